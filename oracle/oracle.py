@@ -1,0 +1,124 @@
+"""ctypes wrapper over oracle/libsc_oracle.so -- CPU ORACLE (test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (sea-current_amd/) never does.
+See oracle/sc_oracle.h for the semantics and the parity status of each function.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EDT_INF = 2**31 - 1
+G_INF = 0xFFFFFFFF
+OK, NO_PATH, BAD_ENDPOINT, PATH_TRUNCATED = 0, 1, 2, 3
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libsc_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libsc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.sco_astar.restype = C.c_int
+        _LIB.sco_toppra.restype = C.c_int
+        _LIB.sco_toppra_sample.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def edt(occ, exact=True):
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    H, W = occ.shape
+    d2 = np.empty((H, W), dtype=np.int32)
+    fn = lib().sco_edt_exact if exact else lib().sco_edt_brute
+    fn(_p(occ, C.c_uint8), C.c_int(W), C.c_int(H), _p(d2, C.c_int32))
+    return d2
+
+
+def moves(d2, r2=0):
+    d2 = np.ascontiguousarray(d2, dtype=np.int32)
+    H, W = d2.shape
+    m = np.empty((H, W), dtype=np.uint8)
+    lib().sco_moves(_p(d2, C.c_int32), C.c_int(W), C.c_int(H), C.c_int32(r2), _p(m, C.c_uint8))
+    return m
+
+
+def astar(d2, start, goal, r2=0, Lmax=None, want_g=False):
+    d2 = np.ascontiguousarray(d2, dtype=np.int32)
+    H, W = d2.shape
+    if Lmax is None:
+        Lmax = W * H
+    path = np.full(Lmax, -1, dtype=np.int32)
+    g = np.empty((H, W), dtype=np.uint32) if want_g else None
+    ln, cost, ex = C.c_int32(0), C.c_int32(-1), C.c_int64(0)
+    st = lib().sco_astar(_p(d2, C.c_int32), C.c_int(W), C.c_int(H), C.c_int32(r2), C.c_int32(int(start)),
+                         C.c_int32(int(goal)), C.c_int(Lmax), _p(path, C.c_int32), C.byref(ln), C.byref(cost),
+                         _p(g, C.c_uint32), C.byref(ex))
+    out = dict(status=st, len=ln.value, cost=cost.value, expanded=ex.value,
+               path=path[:min(ln.value, Lmax)].copy() if st in (OK,) else path[:0].copy())
+    if want_g:
+        out["g"] = g
+    return out
+
+
+def astar_batch(d2, start, goal, r2=0, Lmax=4096, nthreads=1):
+    d2 = np.ascontiguousarray(d2, dtype=np.int32)
+    H, W = d2.shape
+    start = np.ascontiguousarray(start, dtype=np.int32)
+    goal = np.ascontiguousarray(goal, dtype=np.int32)
+    Q = start.shape[0]
+    path = np.full((Q, Lmax), -1, dtype=np.int32)
+    ln = np.zeros(Q, dtype=np.int32)
+    cost = np.zeros(Q, dtype=np.int32)
+    status = np.zeros(Q, dtype=np.int32)
+    ex = np.zeros(Q, dtype=np.int64)
+    lib().sco_astar_batch(_p(d2, C.c_int32), C.c_int(W), C.c_int(H), C.c_int32(r2), _p(start, C.c_int32),
+                          _p(goal, C.c_int32), C.c_int(Q), C.c_int(Lmax), _p(path, C.c_int32), _p(ln, C.c_int32),
+                          _p(cost, C.c_int32), _p(status, C.c_int32), _p(ex, C.c_int64), C.c_int(nthreads))
+    return dict(path=path, len=ln, cost=cost, status=status, expanded=ex)
+
+
+def toppra(p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, N=100, sd_start=0.0, sd_end=0.0):
+    """One plan.  vlim_*: [N+1, dof] (or [dof], broadcast); alim_*: [dof]."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    p0, p1, v0, v1, alim_lo, alim_hi = map(f, (p0, p1, v0, v1, alim_lo, alim_hi))
+    dof = p0.shape[0]
+    vlim_lo = f(np.broadcast_to(f(vlim_lo), (N + 1, dof)))
+    vlim_hi = f(np.broadcast_to(f(vlim_hi), (N + 1, dof)))
+    K = np.zeros((N + 1, 2)); x = np.zeros(N + 1); u = np.zeros(N); t = np.zeros(N + 1)
+    d = C.c_double
+    st = lib().sco_toppra(C.c_int(dof), C.c_int(N), _p(p0, d), _p(p1, d), _p(v0, d), _p(v1, d), _p(vlim_lo, d),
+                          _p(vlim_hi, d), _p(alim_lo, d), _p(alim_hi, d), d(sd_start), d(sd_end),
+                          _p(K, d), _p(x, d), _p(u, d), _p(t, d))
+    return dict(status=st, K=K, x=x, u=u, t=t)
+
+
+def toppra_sample(p0, p1, v0, v1, x, t, dt, max_len=None):
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    p0, p1, v0, v1, x, t = map(f, (p0, p1, v0, v1, x, t))
+    dof = p0.shape[0]
+    N = x.shape[0] - 1
+    if max_len is None:
+        max_len = int(np.ceil(t[-1] / dt)) + 1
+    pos = np.zeros((dof, max_len), dtype=np.float32)
+    vel = np.zeros_like(pos); acc = np.zeros_like(pos)
+    times = np.zeros(max_len)
+    d = C.c_double
+    n = lib().sco_toppra_sample(C.c_int(dof), C.c_int(N), _p(p0, d), _p(p1, d), _p(v0, d), _p(v1, d), _p(x, d),
+                                _p(t, d), d(dt), C.c_int(max_len), _p(pos, C.c_float), _p(vel, C.c_float),
+                                _p(acc, C.c_float), _p(times, d))
+    m = min(n, max_len)
+    return dict(length=n, pos=pos[:, :m], vel=vel[:, :m], acc=acc[:, :m], time=times[:m])

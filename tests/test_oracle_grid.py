@@ -1,0 +1,184 @@
+"""CPU oracle self-checks: exact EDT vs the brute-force definition, A* optimality and the
+canonical g-field / parent rule (definitional oracles -- the reference has no grid path)."""
+import heapq
+
+import numpy as np
+import pytest
+
+from sea_current_amd import synth
+
+DX = [1, -1, 0, 0, 1, -1, 1, -1]
+DY = [0, 0, 1, -1, 1, 1, -1, -1]
+WC = [10, 10, 10, 10, 14, 14, 14, 14]
+
+
+@pytest.mark.parametrize("W,H,p", [(1, 1, 0.5), (7, 5, 0.3), (16, 16, 0.1), (33, 65, 0.05), (64, 64, 0.2), (97, 31, 0.01)])
+def test_edt_exact_equals_brute(oracle, W, H, p):
+    rng = np.random.default_rng(W * 1000 + H)
+    occ = (rng.random((H, W)) < p).astype(np.uint8)
+    assert np.array_equal(oracle.edt(occ, exact=True), oracle.edt(occ, exact=False))
+
+
+def test_edt_edge_cases(oracle):
+    occ = np.zeros((9, 13), np.uint8)
+    assert np.all(oracle.edt(occ) == oracle.EDT_INF)  # empty grid
+    assert np.all(oracle.edt(np.ones((9, 13), np.uint8)) == 0)  # full grid
+    occ[4, 6] = 255  # any non-zero byte is an obstacle
+    d2 = oracle.edt(occ)
+    yy, xx = np.mgrid[0:9, 0:13]
+    assert np.array_equal(d2, (yy - 4) ** 2 + (xx - 6) ** 2)
+    # single obstacle in a corner of a long thin grid (max distances)
+    occ = np.zeros((1, 300), np.uint8); occ[0, 0] = 1
+    assert np.array_equal(oracle.edt(occ)[0], np.arange(300) ** 2)
+
+
+def test_edt_exact_equals_brute_blocks(oracle):
+    occ = synth.block_grid(96, 80, 0.2, seed=5, smin=3, smax=20)
+    assert np.array_equal(oracle.edt(occ, exact=True), oracle.edt(occ, exact=False))
+
+
+def _dijkstra(trav, start):
+    """Independent pure-Python Dijkstra (no heuristic) with the same move rules."""
+    H, W = trav.shape
+    g = np.full(W * H, np.iinfo(np.int64).max, dtype=np.int64)
+    g[start] = 0
+    pq = [(0, start)]
+    while pq:
+        d, c = heapq.heappop(pq)
+        if d != g[c]:
+            continue
+        x, y = c % W, c // W
+        for k in range(8):
+            nx, ny = x + DX[k], y + DY[k]
+            if not (0 <= nx < W and 0 <= ny < H) or not trav[ny, nx]:
+                continue
+            if k >= 4 and not (trav[y, nx] and trav[ny, x]):
+                continue
+            n = ny * W + nx
+            if d + WC[k] < g[n]:
+                g[n] = d + WC[k]
+                heapq.heappush(pq, (d + WC[k], n))
+    return g
+
+
+def _check_query(oracle, d2, r2, start, goal):
+    H, W = d2.shape
+    trav = d2 >= max(r2, 1)
+    r = oracle.astar(d2, start, goal, r2=r2, want_g=True)
+    gs = _dijkstra(trav, start)
+    if gs[goal] == np.iinfo(np.int64).max:
+        assert r["status"] == oracle.NO_PATH
+        # E = whole component, g = g* there
+        reach = gs != np.iinfo(np.int64).max
+        assert np.array_equal(r["g"].ravel()[reach].astype(np.int64), gs[reach])
+        assert np.all(r["g"].ravel()[~reach] == oracle.G_INF)
+        return r
+    assert r["status"] == oracle.OK and r["cost"] == gs[goal]
+    # canonical g field: g* on E, min over E-parents elsewhere
+    gx, gy = goal % W, goal // W
+    xs, ys = np.arange(W * H) % W, np.arange(W * H) // W
+    dx, dy = np.abs(xs - gx), np.abs(ys - gy)
+    h = 10 * np.maximum(dx, dy) + 4 * np.minimum(dx, dy)
+    INF = np.iinfo(np.int64).max
+    inE = (gs != INF) & (np.where(gs != INF, gs, 0) + h <= gs[goal])
+    expect = np.full(W * H, oracle.G_INF, dtype=np.uint64)
+    expect[inE] = gs[inE]
+    for c in np.flatnonzero(inE):
+        x, y = c % W, c // W
+        for k in range(8):
+            nx, ny = x + DX[k], y + DY[k]
+            if not (0 <= nx < W and 0 <= ny < H) or not trav[ny, nx]:
+                continue
+            if k >= 4 and not (trav[y, nx] and trav[ny, x]):
+                continue
+            n = ny * W + nx
+            if not inE[n]:
+                expect[n] = min(expect[n], gs[c] + WC[k])
+    assert np.array_equal(r["g"].ravel().astype(np.uint64), expect)
+    assert r["expanded"] == int(inE.sum())
+    # path: starts/ends right, legal moves, cost adds up, follows the canonical parent
+    p = r["path"]
+    assert p[0] == start and p[-1] == goal and len(p) == r["len"]
+    tot = 0
+    for a, b in zip(p[:-1], p[1:]):
+        ddx, ddy = b % W - a % W, b // W - a // W
+        k = [i for i in range(8) if DX[i] == ddx and DY[i] == ddy][0]
+        assert trav[b // W, b % W] and (k < 4 or (trav[a // W, b % W] and trav[b // W, a % W]))
+        tot += WC[k]
+        # canonical: no smaller direction index also satisfies g[n] + w == g[b]
+        for kk in range(k):
+            nx, ny = b % W - DX[kk], b // W - DY[kk]
+            if not (0 <= nx < W and 0 <= ny < H) or not trav[ny, nx]:
+                continue
+            if kk >= 4 and not (trav[ny, b % W] and trav[b // W, nx]):
+                continue
+            assert int(r["g"][ny, nx]) + WC[kk] != int(r["g"][b // W, b % W]) or r["g"][ny, nx] == oracle.G_INF
+    assert tot == r["cost"]
+    return r
+
+
+@pytest.mark.parametrize("seed,p,r2", [(1, 0.1, 0), (2, 0.25, 0), (3, 0.35, 0), (4, 0.05, 2), (5, 0.02, 5)])
+def test_astar_canonical(oracle, seed, p, r2):
+    rng = np.random.default_rng(seed)
+    W, H = 40, 28
+    occ = (rng.random((H, W)) < p).astype(np.uint8)
+    d2 = oracle.edt(occ)
+    free = np.flatnonzero((d2 >= max(r2, 1)).ravel())
+    for _ in range(12):
+        s, g = rng.choice(free, 2)
+        _check_query(oracle, d2, r2, int(s), int(g))
+
+
+def test_astar_edge_cases(oracle):
+    occ = np.zeros((8, 8), np.uint8)
+    occ[:, 4] = 1  # wall: no path
+    d2 = oracle.edt(occ)
+    r = _check_query(oracle, d2, 0, 0, 7)
+    assert r["status"] == oracle.NO_PATH
+    # start == goal
+    r = oracle.astar(d2, 9, 9)
+    assert r["status"] == oracle.OK and r["cost"] == 0 and list(r["path"]) == [9]
+    # blocked / out-of-range endpoints
+    assert oracle.astar(d2, 4, 0)["status"] == oracle.BAD_ENDPOINT
+    assert oracle.astar(d2, 0, 64)["status"] == oracle.BAD_ENDPOINT
+    assert oracle.astar(d2, -1, 0)["status"] == oracle.BAD_ENDPOINT
+    # truncated path: len reported, status 3
+    occ = np.zeros((1, 50), np.uint8)
+    d2 = oracle.edt(np.pad(occ, ((0, 1), (0, 0)), constant_values=1))[:1]
+    d2 = np.ascontiguousarray(d2)
+    r = oracle.astar(d2, 0, 49, Lmax=10)
+    assert r["status"] == oracle.PATH_TRUNCATED and r["len"] == 50
+    # no corner cutting: diagonal gap between two obstacles is closed
+    occ = np.zeros((3, 3), np.uint8); occ[0, 1] = 1; occ[1, 0] = 1
+    d2 = oracle.edt(occ)
+    assert oracle.astar(d2, 0, 8)["status"] == oracle.NO_PATH
+
+
+def test_moves_matches_rules(oracle):
+    rng = np.random.default_rng(11)
+    occ = (rng.random((20, 24)) < 0.3).astype(np.uint8)
+    d2 = oracle.edt(occ)
+    m = oracle.moves(d2, 0)
+    trav = d2 >= 1
+    for y in range(20):
+        for x in range(24):
+            e = 0
+            if trav[y, x]:
+                for k in range(8):
+                    nx, ny = x + DX[k], y + DY[k]
+                    if 0 <= nx < 24 and 0 <= ny < 20 and trav[ny, nx] and (k < 4 or (trav[y, nx] and trav[ny, x])):
+                        e |= 1 << k
+            assert m[y, x] == e
+
+
+def test_batch_equals_single_and_threads(oracle):
+    occ = synth.salt_grid(64, 64, 0.15, seed=3)
+    d2 = oracle.edt(occ)
+    s, g = synth.queries(d2 >= 1, 24)
+    b1 = oracle.astar_batch(d2, s, g, Lmax=256, nthreads=1)
+    b4 = oracle.astar_batch(d2, s, g, Lmax=256, nthreads=4)
+    for k in ("path", "len", "cost", "status", "expanded"):
+        assert np.array_equal(b1[k], b4[k])
+    for q in range(24):
+        r = oracle.astar(d2, s[q], g[q])
+        assert r["cost"] == b1["cost"][q] and np.array_equal(r["path"], b1["path"][q, :r["len"]])
