@@ -1,0 +1,171 @@
+/*
+ * sea_current_hip.h -- C ABI of libsea_current_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for sea-current's planning hot path.  The
+ * reference (turtle-robotics/sea-current @ 2024-10-16) is a header-only C++20
+ * library with NO FFI of its own; the boundary it exposes is the `turtle::sc`
+ * API of sea_current.hpp.  Each entry point below names the reference
+ * interface whose work it takes over (file:line relative to the reference
+ * root).  The C++ successor header sea-current_amd/sea_current.hpp keeps the
+ * reference signatures and calls these functions; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types.
+ *   - functions without a suffix take DEVICE pointers and enqueue work on the
+ *     context's stream without synchronising (inputs already resident in HBM);
+ *     `_host` variants take host pointers, copy, run, copy back and synchronise.
+ *   - every function returns an sc_status (0 = ok) and never exits the process
+ *     (the reference's SC_ASSERT calls std::exit(1), sea_current.hpp:34-52).
+ *   - a context is bound to one GPU and one stream; calls on one context are
+ *     serialised on its stream, contexts are independent (one per host
+ *     thread / rank).  No allocation happens in steady state: scratch is owned
+ *     by the context and only grows.
+ */
+#ifndef SEA_CURRENT_HIP_H
+#define SEA_CURRENT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+
+typedef struct sc_ctx sc_ctx;
+
+typedef enum {
+    SC_OK = 0,
+    SC_ERR_INVALID = 1,  /* bad argument (null pointer, non-positive size, W or H too large) */
+    SC_ERR_HIP = 2,      /* a HIP runtime call failed; see sc_last_error */
+    SC_ERR_NOMEM = 3,    /* device allocation failed */
+    SC_ERR_NO_DEVICE = 4 /* no usable gfx950 device */
+} sc_status;
+
+/* per-query status written by sc_astar_batch (mirrors the reference planner's
+ * std::optional result: nullopt == SC_Q_NO_PATH, sea_current.hpp:1383-1385) */
+typedef enum {
+    SC_Q_OK = 0,
+    SC_Q_NO_PATH = 1,
+    SC_Q_BAD_ENDPOINT = 2, /* start/goal out of range or not traversable */
+    SC_Q_TRUNCATED = 3     /* path longer than Lmax: len holds the needed length, path is unspecified */
+} sc_query_status;
+
+/* kernels timed by sc_ctx_set_timing (indices for sc_ctx_get_timing) */
+typedef enum {
+    SC_K_EDT_COLBITS = 0, /* occupancy bytes -> transposed per-band column bit words */
+    SC_K_EDT_BAND = 1,    /* per 32-row band: vertical distances + exact row envelope -> d2 */
+    SC_K_MOVES = 2,       /* d2 + clearance -> legal-move byte per cell */
+    SC_K_ASTAR = 3,       /* batched A*: one wavefront per query */
+    SC_K_TOPPRA = 4,      /* batched TOPP-RA: computeParams + backward + forward sweep */
+    SC_K_TOPPRA_SAMPLE = 5,
+    SC_K_COUNT = 6
+} sc_kernel_id;
+
+#define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
+#define SC_MAX_DIM 8192      /* W, H <= SC_MAX_DIM (LDS row buffers) */
+
+int sc_abi_version(void);
+const char* sc_status_string(int status);
+/* message of the last failing HIP call on this context ("" if none) */
+const char* sc_last_error(const sc_ctx* ctx);
+
+/* ---- context ----------------------------------------------------------- */
+int sc_ctx_create(int device, sc_ctx** out);
+int sc_ctx_destroy(sc_ctx* ctx);
+/* Use the caller's hipStream_t (e.g. torch's current stream) instead of the
+ * context's own; NULL means HIP's null (legacy default) stream. */
+int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);
+/* Go back to the context's own non-blocking stream (the default after create). */
+int sc_ctx_use_own_stream(sc_ctx* ctx);
+int sc_ctx_synchronize(sc_ctx* ctx);
+/* Kernel timing: when enabled every kernel launch is bracketed by HIP events on
+ * the context's stream; sc_ctx_get_timing synchronises and returns the summed
+ * device time and the number of launches since the last reset. */
+int sc_ctx_set_timing(sc_ctx* ctx, int enable);
+int sc_ctx_reset_timing(sc_ctx* ctx);
+int sc_ctx_get_timing(sc_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+/* Bytes of device scratch currently owned by the context. */
+int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes);
+
+/* ---- EDT ---------------------------------------------------------------
+ * Exact squared Euclidean distance transform of `batch` occupancy grids.
+ *   occ : uint8 [batch][H][W] row-major, != 0 means occupied
+ *   d2  : int32 [batch][H][W]; SC_EDT_INF everywhere if a grid has no obstacle
+ * Takes over the collision/clearance queries the reference answers by ray
+ * casting and segment tests: obstacle::contains (sea_current.hpp:201-251),
+ * planning_space::is_obstacle (:1274-1280), ::is_free (:1289-1292), ::cost
+ * (:1315-1326).  The reference has no grid; the result is defined
+ * mathematically (oracle/sc_oracle.h). */
+int sc_edt_u8_i32(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
+int sc_edt_u8_i32_host(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
+
+/* Legal-move mask per cell: bit d set iff move d (dx={1,-1,0,0,1,-1,1,-1},
+ * dy={0,0,1,-1,1,1,-1,-1}) out of the cell is allowed: both cells have
+ * d2 >= max(r2_clear,1) and, for diagonals, both side cells too. */
+int sc_moves_i32_u8(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear, uint8_t* moves);
+
+/* ---- batched A* --------------------------------------------------------
+ * Q independent start->goal queries on one grid; 8-connected, costs 10/14,
+ * octile heuristic, no corner cutting, canonical parent rule (sc_oracle.h).
+ *   d2          : int32 [H][W] from sc_edt_u8_i32
+ *   start, goal : int32 [Q] linear cell indices (y*W + x)
+ *   path        : int32 [Q][Lmax], cells start..goal in path[q][0..len[q])
+ *   len, cost, status : int32 [Q]  (cost = -1, len = 0 when there is no path)
+ * Takes over planning_space::fast_marching_trees (sea_current.hpp:1339-1407)
+ * with its helpers near (:1328-1337) and sample_free (:1294-1313): same role
+ * (start, goal) -> optional waypoint list, on a grid instead of Halton samples. */
+int sc_astar_batch(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
+                   const int32_t* start, const int32_t* goal, int Q, int Lmax,
+                   int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
+int sc_astar_batch_host(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
+                        const int32_t* start, const int32_t* goal, int Q, int Lmax,
+                        int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
+/* Node expansions of the last sc_astar_batch call on this context (synchronises). */
+int sc_astar_last_expansions(sc_ctx* ctx, int64_t* expansions);
+/* Debug/parity: canonical g field (uint32 [H][W], 0xFFFFFFFF = unreached) of ONE query. */
+int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
+                    int32_t start, int32_t goal, uint32_t* gfield, int32_t* cost, int32_t* status);
+
+/* ---- batched TOPP-RA ---------------------------------------------------
+ * P independent plans; path of plan p is the 2-knot cubic Hermite spline the
+ * reference builds in gen_vel_prof<N> (sea_current.hpp:1213-1220) from
+ * p0,p1 (positions) and v0,v1 (path tangents), all [P][dof] fp64.
+ *   vlim_lo/hi : [P][dof] if vlim_per_stage == 0, else [P][N+1][dof] (limits
+ *                evaluated at each gridpoint, LinearJointVelocityVarying,
+ *                sea_current.hpp:1177-1188)
+ *   alim_lo/hi : [P][dof]
+ *   K [P][N+1][2], x [P][N+1] (= sdot^2), u [P][N], t [P][N+1], status [P]
+ *   status: 0 ok, 1 backward pass infeasible, 2 forward pass infeasible
+ * One kernel fuses LinearConstraint::computeParams of both constraints with
+ * the backward (controllable sets) and forward sweeps of
+ * TOPPRA::computePathParametrization(0,0) (:1224-1225) and the knot times of
+ * parametrizer::Spline (:1233).  dof <= 16. */
+int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
+                            const double* p0, const double* p1, const double* v0, const double* v1,
+                            const double* vlim_lo, const double* vlim_hi, int vlim_per_stage,
+                            const double* alim_lo, const double* alim_hi,
+                            double sd_start, double sd_end,
+                            double* K, double* x, double* u, double* t, int32_t* status);
+int sc_toppra_hermite_batch_host(sc_ctx* ctx, int P, int dof, int N,
+                                 const double* p0, const double* p1, const double* v0, const double* v1,
+                                 const double* vlim_lo, const double* vlim_hi, int vlim_per_stage,
+                                 const double* alim_lo, const double* alim_hi,
+                                 double sd_start, double sd_end,
+                                 double* K, double* x, double* u, double* t, int32_t* status);
+/* Spline parametrizer + uniform sampling (sea_current.hpp:1233-1262):
+ *   length[p] = ceil(T_p/dt); samples at linspace(0, T_p, length[p]);
+ *   pos/vel/acc float32 [P][dof][max_len] (the reference casts to VectorXf),
+ *   times fp64 [P][max_len].  Only min(length, max_len) samples are written. */
+int sc_toppra_sample_batch(sc_ctx* ctx, int P, int dof, int N,
+                           const double* p0, const double* p1, const double* v0, const double* v1,
+                           const double* x, const double* t, double dt, int max_len,
+                           float* pos, float* vel, float* acc, double* times, int32_t* length);
+int sc_toppra_sample_batch_host(sc_ctx* ctx, int P, int dof, int N,
+                                const double* p0, const double* p1, const double* v0, const double* v1,
+                                const double* x, const double* t, double dt, int max_len,
+                                float* pos, float* vel, float* acc, double* times, int32_t* length);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,260 @@
+// ctx.hip -- context, stream, scratch, launch timing and the `_host` convenience wrappers.
+#include "sc_internal.h"
+
+extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
+
+extern "C" const char* sc_status_string(int s) {
+    switch (s) {
+        case SC_OK: return "ok";
+        case SC_ERR_INVALID: return "invalid argument";
+        case SC_ERR_HIP: return "HIP runtime error";
+        case SC_ERR_NOMEM: return "out of device memory";
+        case SC_ERR_NO_DEVICE: return "no usable device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* sc_last_error(const sc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int sc_ctx_create(int device, sc_ctx** out) {
+    if (!out) return SC_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SC_ERR_NO_DEVICE;
+    sc_ctx* c = new sc_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SC_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SC_OK;
+}
+
+static void free_scratch(sc_scratch* s) {
+    if (s->p) (void)hipFree(s->p);
+    s->p = nullptr;
+    s->bytes = 0;
+}
+
+extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
+    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats);
+    for (auto& s : ctx->staging) free_scratch(&s);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_set_stream(sc_ctx* ctx, void* s) {
+    if (!ctx) return SC_ERR_INVALID;
+    ctx->stream = (hipStream_t)s;
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_use_own_stream(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    ctx->stream = ctx->own_stream;
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_synchronize(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {
+    if (bytes <= s->bytes) return SC_OK;
+    if (s->p) {
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SC_HIP(ctx, hipFree(s->p));
+        s->p = nullptr;
+        s->bytes = 0;
+    }
+    SC_HIP(ctx, hipMalloc(&s->p, bytes));
+    s->bytes = bytes;
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes) {
+    if (!ctx || !bytes) return SC_ERR_INVALID;
+    size_t b = ctx->colbits.bytes + ctx->moves.bytes + ctx->gslots.bytes + ctx->buckets.bytes + ctx->qstats.bytes;
+    for (auto& s : ctx->staging) b += s.bytes;
+    *bytes = (int64_t)b;
+    return SC_OK;
+}
+
+// ---- timing ---------------------------------------------------------------
+static hipEvent_t get_event(sc_ctx* ctx) {
+    if (!ctx->ev_pool.empty()) {
+        hipEvent_t e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int sc_time_begin(sc_ctx* ctx, int kid) {
+    if (!ctx->timing) return -1;
+    sc_ctx::pending_ev p{kid, get_event(ctx), get_event(ctx)};
+    (void)hipEventRecord(p.a, ctx->stream);
+    ctx->pending.push_back(p);
+    return (int)ctx->pending.size() - 1;
+}
+
+void sc_time_end(sc_ctx* ctx, int token) {
+    if (token < 0) return;
+    (void)hipEventRecord(ctx->pending[token].b, ctx->stream);
+}
+
+static void drain_timing(sc_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->t_ms[p.kid] += ms;
+            ctx->t_n[p.kid] += 1;
+        }
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int sc_ctx_set_timing(sc_ctx* ctx, int enable) {
+    if (!ctx) return SC_ERR_INVALID;
+    drain_timing(ctx);
+    ctx->timing = enable ? 1 : 0;
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_reset_timing(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    drain_timing(ctx);
+    for (int i = 0; i < SC_K_COUNT; ++i) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
+    return SC_OK;
+}
+
+extern "C" int sc_ctx_get_timing(sc_ctx* ctx, int kid, double* total_ms, int64_t* launches) {
+    if (!ctx || kid < 0 || kid >= SC_K_COUNT) return SC_ERR_INVALID;
+    drain_timing(ctx);
+    if (total_ms) *total_ms = ctx->t_ms[kid];
+    if (launches) *launches = ctx->t_n[kid];
+    return SC_OK;
+}
+
+// ---- host wrappers ---------------------------------------------------------
+#define STAGE(i, bytes)                                                        \
+    do {                                                                       \
+        int r_ = sc_scratch_reserve(ctx, &ctx->staging[i], (bytes));           \
+        if (r_ != SC_OK) return r_;                                            \
+    } while (0)
+#define H2D(i, src, bytes) SC_HIP(ctx, hipMemcpyAsync(ctx->staging[i].p, (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
+#define D2H(dst, i, bytes) SC_HIP(ctx, hipMemcpyAsync((dst), ctx->staging[i].p, (bytes), hipMemcpyDeviceToHost, ctx->stream))
+
+extern "C" int sc_edt_u8_i32_host(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2) {
+    if (!ctx || !occ || !d2 || W <= 0 || H <= 0 || batch <= 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)W * H * batch;
+    STAGE(0, n);
+    STAGE(1, n * 4);
+    H2D(0, occ, n);
+    int r = sc_edt_u8_i32(ctx, (const uint8_t*)ctx->staging[0].p, W, H, batch, (int32_t*)ctx->staging[1].p);
+    if (r != SC_OK) return r;
+    D2H(d2, 1, n * 4);
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_astar_batch_host(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2,
+                                   const int32_t* start, const int32_t* goal, int Q, int Lmax,
+                                   int32_t* path, int32_t* len, int32_t* cost, int32_t* status) {
+    if (!ctx || !d2 || !start || !goal || !path || !len || !cost || !status || W <= 0 || H <= 0 || Q < 0 || Lmax <= 0)
+        return SC_ERR_INVALID;
+    if (Q == 0) return SC_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)W * H;
+    STAGE(0, n * 4); STAGE(1, (size_t)Q * 4); STAGE(2, (size_t)Q * 4);
+    STAGE(3, (size_t)Q * Lmax * 4); STAGE(4, (size_t)Q * 4); STAGE(5, (size_t)Q * 4); STAGE(6, (size_t)Q * 4);
+    H2D(0, d2, n * 4); H2D(1, start, (size_t)Q * 4); H2D(2, goal, (size_t)Q * 4);
+    int r = sc_astar_batch(ctx, (const int32_t*)ctx->staging[0].p, W, H, r2, (const int32_t*)ctx->staging[1].p,
+                           (const int32_t*)ctx->staging[2].p, Q, Lmax, (int32_t*)ctx->staging[3].p,
+                           (int32_t*)ctx->staging[4].p, (int32_t*)ctx->staging[5].p, (int32_t*)ctx->staging[6].p);
+    if (r != SC_OK) return r;
+    D2H(path, 3, (size_t)Q * Lmax * 4); D2H(len, 4, (size_t)Q * 4); D2H(cost, 5, (size_t)Q * 4); D2H(status, 6, (size_t)Q * 4);
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_toppra_hermite_batch_host(sc_ctx* ctx, int P, int dof, int N,
+                                            const double* p0, const double* p1, const double* v0, const double* v1,
+                                            const double* vlim_lo, const double* vlim_hi, int vlim_per_stage,
+                                            const double* alim_lo, const double* alim_hi,
+                                            double sd_start, double sd_end,
+                                            double* K, double* x, double* u, double* t, int32_t* status) {
+    if (!ctx || P <= 0 || dof <= 0 || N <= 0 || !p0 || !p1 || !v0 || !v1 || !vlim_lo || !vlim_hi || !alim_lo ||
+        !alim_hi || !K || !x || !u || !t || !status)
+        return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t pd = (size_t)P * dof * 8, vl = vlim_per_stage ? pd * (N + 1) : pd;
+    // one staging block: inputs then outputs
+    size_t off_in[8] = {0, pd, 2 * pd, 3 * pd, 4 * pd, 4 * pd + vl, 4 * pd + 2 * vl, 5 * pd + 2 * vl};
+    size_t in_bytes = 6 * pd + 2 * vl;
+    size_t oK = in_bytes, ox = oK + (size_t)P * (N + 1) * 16, ou = ox + (size_t)P * (N + 1) * 8,
+           ot = ou + (size_t)P * N * 8, os = ot + (size_t)P * (N + 1) * 8, total = os + (size_t)P * 4;
+    STAGE(0, total);
+    char* b = (char*)ctx->staging[0].p;
+    const void* src[8] = {p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi};
+    size_t sz[8] = {pd, pd, pd, pd, vl, vl, pd, pd};
+    for (int i = 0; i < 8; ++i) SC_HIP(ctx, hipMemcpyAsync(b + off_in[i], src[i], sz[i], hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_toppra_hermite_batch(ctx, P, dof, N, (double*)(b + off_in[0]), (double*)(b + off_in[1]),
+                                    (double*)(b + off_in[2]), (double*)(b + off_in[3]), (double*)(b + off_in[4]),
+                                    (double*)(b + off_in[5]), vlim_per_stage, (double*)(b + off_in[6]),
+                                    (double*)(b + off_in[7]), sd_start, sd_end, (double*)(b + oK), (double*)(b + ox),
+                                    (double*)(b + ou), (double*)(b + ot), (int32_t*)(b + os));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(K, b + oK, (size_t)P * (N + 1) * 16, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(x, b + ox, (size_t)P * (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(u, b + ou, (size_t)P * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(t, b + ot, (size_t)P * (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(status, b + os, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_toppra_sample_batch_host(sc_ctx* ctx, int P, int dof, int N,
+                                           const double* p0, const double* p1, const double* v0, const double* v1,
+                                           const double* x, const double* t, double dt, int max_len,
+                                           float* pos, float* vel, float* acc, double* times, int32_t* length) {
+    if (!ctx || P <= 0 || dof <= 0 || N <= 0 || max_len <= 0 || !p0 || !p1 || !v0 || !v1 || !x || !t || !pos ||
+        !vel || !acc || !times || !length)
+        return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t pd = (size_t)P * dof * 8, xs = (size_t)P * (N + 1) * 8;
+    size_t o[6] = {0, pd, 2 * pd, 3 * pd, 4 * pd, 4 * pd + xs};
+    size_t in_bytes = 4 * pd + 2 * xs;
+    size_t fb = (size_t)P * dof * max_len * 4;
+    size_t opos = in_bytes, ovel = opos + fb, oacc = ovel + fb, otim = oacc + fb, olen = otim + (size_t)P * max_len * 8,
+           total = olen + (size_t)P * 4;
+    STAGE(1, total);
+    char* b = (char*)ctx->staging[1].p;
+    const void* src[6] = {p0, p1, v0, v1, x, t};
+    size_t sz[6] = {pd, pd, pd, pd, xs, xs};
+    for (int i = 0; i < 6; ++i) SC_HIP(ctx, hipMemcpyAsync(b + o[i], src[i], sz[i], hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_toppra_sample_batch(ctx, P, dof, N, (double*)(b + o[0]), (double*)(b + o[1]), (double*)(b + o[2]),
+                                   (double*)(b + o[3]), (double*)(b + o[4]), (double*)(b + o[5]), dt, max_len,
+                                   (float*)(b + opos), (float*)(b + ovel), (float*)(b + oacc), (double*)(b + otim),
+                                   (int32_t*)(b + olen));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(pos, b + opos, fb, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(vel, b + ovel, fb, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(acc, b + oacc, fb, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(times, b + otim, (size_t)P * max_len * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(length, b + olen, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}

@@ -1,0 +1,59 @@
+// sc_internal.h -- context, scratch and launch-timing plumbing shared by the HIP sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/sea_current_hip.h"
+
+struct sc_scratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct sc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[256] = {0};
+    // timing
+    int timing = 0;
+    struct pending_ev { int kid; hipEvent_t a, b; };
+    std::vector<pending_ev> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double t_ms[SC_K_COUNT] = {0};
+    int64_t t_n[SC_K_COUNT] = {0};
+    // scratch (grow-only)
+    sc_scratch colbits;     // EDT: uint32 [batch][nb][W]
+    sc_scratch moves;       // A*: uint8 [H][W]
+    sc_scratch gslots;      // A*: uint32 [S][cells]
+    sc_scratch buckets;     // A*: uint32 [S][32][cap]
+    sc_scratch qstats;      // A*: int32 expanded[Q] + flags
+    sc_scratch staging[8];  // _host wrappers
+    int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
+    size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
+    int last_Q = 0;
+};
+
+#define SC_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+                     hipGetErrorString(e_));                                               \
+            return e_ == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_HIP;                  \
+        }                                                                                  \
+    } while (0)
+
+int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes);
+
+// RAII-free timing bracket: t = sc_time_begin(ctx, kid); launch...; sc_time_end(ctx, t)
+int sc_time_begin(sc_ctx* ctx, int kid);
+void sc_time_end(sc_ctx* ctx, int token);
+
+// kernels' host launchers (defined in the respective .hip files)
+int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
+int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, uint8_t* moves);

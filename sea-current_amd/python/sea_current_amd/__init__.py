@@ -1,1 +1,257 @@
-"""sea_current_amd -- host-side Python plumbing over libsea_current_hip.so (placeholder, filled below)."""
+"""sea_current_amd -- Python plumbing over libsea_current_hip.so (MI355X / gfx950).
+
+The product is the C-ABI library (include/sea_current_hip.h) and the C++ header
+sea-current_amd/sea_current.hpp; this module only binds the C ABI with ctypes so that
+tests/ and bench.py can drive it with torch device tensors.  There is NO CPU fallback:
+if the HIP library is missing or no GPU is present, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+NATIVE_DIR = os.path.normpath(os.path.join(_PKG, "..", ".."))          # sea-current_amd/
+REPO_ROOT = os.path.normpath(os.path.join(NATIVE_DIR, ".."))
+LIB_PATH = os.path.join(NATIVE_DIR, "libsea_current_hip.so")
+HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
+
+EDT_INF = 2**31 - 1
+Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE = range(6)
+
+_lib = None
+
+
+class SeaCurrentError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libsea_current_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", NATIVE_DIR, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", NATIVE_DIR])
+    return LIB_PATH
+
+
+_vp, _i, _d, _i64p = C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int64)
+_SIGNATURES = {
+    "sc_abi_version": (C.c_int, []),
+    "sc_status_string": (C.c_char_p, [_i]),
+    "sc_last_error": (C.c_char_p, [_vp]),
+    "sc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "sc_ctx_destroy": (_i, [_vp]),
+    "sc_ctx_set_stream": (_i, [_vp, _vp]),
+    "sc_ctx_use_own_stream": (_i, [_vp]),
+    "sc_ctx_synchronize": (_i, [_vp]),
+    "sc_ctx_set_timing": (_i, [_vp, _i]),
+    "sc_ctx_reset_timing": (_i, [_vp]),
+    "sc_ctx_get_timing": (_i, [_vp, _i, C.POINTER(_d), _i64p]),
+    "sc_ctx_scratch_bytes": (_i, [_vp, _i64p]),
+    "sc_edt_u8_i32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sc_edt_u8_i32_host": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sc_moves_i32_u8": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp]),
+    "sc_astar_batch": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sc_astar_batch_host": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sc_astar_last_expansions": (_i, [_vp, _i64p]),
+    "sc_astar_gfield": (_i, [_vp, _vp, _i, _i, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "sc_toppra_hermite_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
+    "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
+    "sc_toppra_sample_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+    "sc_toppra_sample_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load the in-tree HIP library; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeaCurrentError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "or `make -C sea-current_amd` (there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def _ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (must be contiguous)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+class Context:
+    """One sc_ctx: one GPU, one stream.  `device` is the HIP device ordinal."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        self._l = lib()
+        h = C.c_void_p()
+        st = self._l.sc_ctx_create(device, C.byref(h))
+        if st != 0:
+            raise SeaCurrentError(f"sc_ctx_create(device={device}): {self._l.sc_status_string(st).decode()} "
+                                  "(a gfx950 GPU is required; there is no CPU fallback)")
+        self._h = h
+        self.device = device
+        if use_torch_stream:
+            import torch
+            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise SeaCurrentError(f"{what}: {self._l.sc_status_string(st).decode()}: "
+                                  f"{self._l.sc_last_error(self._h).decode()}")
+
+    def close(self):
+        if self._h:
+            self._l.sc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self._ck(self._l.sc_ctx_set_stream(self._h, C.c_void_p(hip_stream or None)), "sc_ctx_set_stream")
+
+    def use_own_stream(self):
+        self._ck(self._l.sc_ctx_use_own_stream(self._h), "sc_ctx_use_own_stream")
+
+    def synchronize(self):
+        self._ck(self._l.sc_ctx_synchronize(self._h), "sc_ctx_synchronize")
+
+    # -- timing
+    def set_timing(self, on):
+        self._ck(self._l.sc_ctx_set_timing(self._h, int(bool(on))), "sc_ctx_set_timing")
+
+    def reset_timing(self):
+        self._ck(self._l.sc_ctx_reset_timing(self._h), "sc_ctx_reset_timing")
+
+    def get_timing(self, kid):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._ck(self._l.sc_ctx_get_timing(self._h, kid, C.byref(ms), C.byref(n)), "sc_ctx_get_timing")
+        return ms.value, n.value
+
+    def scratch_bytes(self):
+        b = C.c_int64(0)
+        self._ck(self._l.sc_ctx_scratch_bytes(self._h, C.byref(b)), "sc_ctx_scratch_bytes")
+        return b.value
+
+    # -- device-pointer entry points (torch CUDA tensors)
+    def edt(self, occ, out=None):
+        """occ: uint8 [B,H,W] or [H,W] on the GPU -> int32 d2 of the same shape."""
+        import torch
+        assert occ.is_cuda and occ.dtype == torch.uint8
+        o3 = occ if occ.dim() == 3 else occ.unsqueeze(0)
+        B, H, W = o3.shape
+        if out is None:
+            out = torch.empty(o3.shape, dtype=torch.int32, device=occ.device)
+        self._ck(self._l.sc_edt_u8_i32(self._h, _ptr(o3.contiguous()), W, H, B, _ptr(out)), "sc_edt_u8_i32")
+        return out if occ.dim() == 3 else out.view(H, W)
+
+    def moves(self, d2, r2=0):
+        import torch
+        H, W = d2.shape
+        out = torch.empty((H, W), dtype=torch.uint8, device=d2.device)
+        self._ck(self._l.sc_moves_i32_u8(self._h, _ptr(d2), W, H, r2, _ptr(out)), "sc_moves_i32_u8")
+        return out
+
+    def astar_batch(self, d2, start, goal, r2=0, Lmax=4096, out=None):
+        """d2 int32 [H,W]; start/goal int32 [Q] (GPU).  Returns dict of GPU tensors."""
+        import torch
+        H, W = d2.shape
+        Q = start.shape[0]
+        if out is None:
+            out = dict(path=torch.empty((Q, Lmax), dtype=torch.int32, device=d2.device),
+                       len=torch.empty(Q, dtype=torch.int32, device=d2.device),
+                       cost=torch.empty(Q, dtype=torch.int32, device=d2.device),
+                       status=torch.empty(Q, dtype=torch.int32, device=d2.device))
+        self._ck(self._l.sc_astar_batch(self._h, _ptr(d2), W, H, r2, _ptr(start), _ptr(goal), Q, Lmax,
+                                        _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]), _ptr(out["status"])),
+                 "sc_astar_batch")
+        return out
+
+    def astar_last_expansions(self):
+        n = C.c_int64(0)
+        self._ck(self._l.sc_astar_last_expansions(self._h, C.byref(n)), "sc_astar_last_expansions")
+        return n.value
+
+    def astar_gfield(self, d2, start, goal, r2=0):
+        import torch
+        H, W = d2.shape
+        g = torch.empty((H, W), dtype=torch.int32, device=d2.device)
+        cs = torch.empty(2, dtype=torch.int32, device=d2.device)
+        self._ck(self._l.sc_astar_gfield(self._h, _ptr(d2), W, H, r2, int(start), int(goal), _ptr(g),
+                                         cs.data_ptr(), cs.data_ptr() + 4), "sc_astar_gfield")
+        self.synchronize()
+        cost, status = cs.cpu().tolist()
+        if status == Q_TRUNCATED:  # the path itself is not requested (Lmax = 1)
+            status = Q_OK
+        return g.cpu().numpy().view(np.uint32), cost, status
+
+    def toppra(self, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, N=100, sd_start=0.0, sd_end=0.0):
+        """All inputs float64 GPU tensors [P,dof] (vlim may be [P,N+1,dof])."""
+        import torch
+        P, dof = p0.shape
+        per_stage = int(vlim_lo.dim() == 3)
+        dev = p0.device
+        out = dict(K=torch.empty((P, N + 1, 2), dtype=torch.float64, device=dev),
+                   x=torch.empty((P, N + 1), dtype=torch.float64, device=dev),
+                   u=torch.empty((P, N), dtype=torch.float64, device=dev),
+                   t=torch.empty((P, N + 1), dtype=torch.float64, device=dev),
+                   status=torch.empty(P, dtype=torch.int32, device=dev))
+        self._ck(self._l.sc_toppra_hermite_batch(self._h, P, dof, N, _ptr(p0), _ptr(p1), _ptr(v0), _ptr(v1),
+                                                 _ptr(vlim_lo), _ptr(vlim_hi), per_stage, _ptr(alim_lo), _ptr(alim_hi),
+                                                 sd_start, sd_end, _ptr(out["K"]), _ptr(out["x"]), _ptr(out["u"]),
+                                                 _ptr(out["t"]), _ptr(out["status"])), "sc_toppra_hermite_batch")
+        return out
+
+    def toppra_sample(self, p0, p1, v0, v1, x, t, dt, max_len):
+        import torch
+        P, dof = p0.shape
+        N = x.shape[1] - 1
+        dev = p0.device
+        out = dict(pos=torch.zeros((P, dof, max_len), dtype=torch.float32, device=dev),
+                   vel=torch.zeros((P, dof, max_len), dtype=torch.float32, device=dev),
+                   acc=torch.zeros((P, dof, max_len), dtype=torch.float32, device=dev),
+                   time=torch.zeros((P, max_len), dtype=torch.float64, device=dev),
+                   length=torch.empty(P, dtype=torch.int32, device=dev))
+        self._ck(self._l.sc_toppra_sample_batch(self._h, P, dof, N, _ptr(p0), _ptr(p1), _ptr(v0), _ptr(v1), _ptr(x),
+                                                _ptr(t), float(dt), max_len, _ptr(out["pos"]), _ptr(out["vel"]),
+                                                _ptr(out["acc"]), _ptr(out["time"]), _ptr(out["length"])),
+                 "sc_toppra_sample_batch")
+        return out
+
+    # -- host-pointer entry points (numpy)
+    def edt_host(self, occ):
+        occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        o3 = occ if occ.ndim == 3 else occ[None]
+        B, H, W = o3.shape
+        d2 = np.empty(o3.shape, dtype=np.int32)
+        self._ck(self._l.sc_edt_u8_i32_host(self._h, _ptr(o3), W, H, B, _ptr(d2)), "sc_edt_u8_i32_host")
+        return d2 if occ.ndim == 3 else d2[0]
+
+    def astar_batch_host(self, d2, start, goal, r2=0, Lmax=4096):
+        d2 = np.ascontiguousarray(d2, dtype=np.int32)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        goal = np.ascontiguousarray(goal, dtype=np.int32)
+        H, W = d2.shape
+        Q = start.shape[0]
+        out = dict(path=np.full((Q, Lmax), -1, dtype=np.int32), len=np.zeros(Q, np.int32),
+                   cost=np.zeros(Q, np.int32), status=np.zeros(Q, np.int32))
+        self._ck(self._l.sc_astar_batch_host(self._h, _ptr(d2), W, H, r2, _ptr(start), _ptr(goal), Q, Lmax,
+                                             _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]),
+                                             _ptr(out["status"])), "sc_astar_batch_host")
+        return out

@@ -1,0 +1,100 @@
+"""GPU parity: batched HIP A* (through the C ABI) vs the CPU oracle -- bit-exact costs, g fields,
+parent chains (paths), statuses."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import sea_current_amd as sc
+    assert torch.cuda.is_available()
+    c = sc.Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, d2, s, g, r2=0, Lmax=4096):
+    import torch
+    out = ctx.astar_batch(torch.from_numpy(d2).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), r2=r2, Lmax=Lmax)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _compare(gpu, ref, Q):
+    assert np.array_equal(gpu["status"], ref["status"])
+    assert np.array_equal(gpu["cost"], ref["cost"])
+    assert np.array_equal(gpu["len"], ref["len"])
+    for q in range(Q):
+        if ref["status"][q] == 0:
+            L = ref["len"][q]
+            assert np.array_equal(gpu["path"][q, :L], ref["path"][q, :L]), q
+
+
+@pytest.mark.parametrize("W,H,p,r2,seed", [(40, 28, 0.1, 0, 1), (64, 64, 0.25, 0, 2), (97, 61, 0.33, 0, 3),
+                                           (128, 128, 0.05, 4, 4), (256, 256, 0.2, 0, 5)])
+def test_astar_matches_oracle(ctx, oracle, W, H, p, r2, seed):
+    from sea_current_amd import synth
+    occ = synth.salt_grid(W, H, p, seed=seed)
+    d2 = oracle.edt(occ)
+    s, g = synth.queries(d2 >= max(r2, 1), 64, seed=seed)
+    # add cross-component / invalid / trivial queries
+    rng = np.random.default_rng(seed)
+    free = np.flatnonzero((d2 >= max(r2, 1)).ravel()).astype(np.int32)
+    s = np.concatenate([s, rng.choice(free, 16), [free[0], -1, W * H, np.flatnonzero(occ.ravel())[0]]]).astype(np.int32)
+    g = np.concatenate([g, rng.choice(free, 16), [free[0], free[0], free[0], free[0]]]).astype(np.int32)
+    Q = s.shape[0]
+    ref = oracle.astar_batch(d2, s, g, r2=r2, Lmax=2048, nthreads=4)
+    _compare(_run(ctx, d2, s, g, r2=r2, Lmax=2048), ref, Q)
+
+
+def test_astar_gfield_bit_exact(ctx, oracle):
+    import torch
+    from sea_current_amd import synth
+    occ = synth.block_grid(160, 120, 0.2, seed=3, smin=3, smax=24)
+    d2 = oracle.edt(occ)
+    s, g = synth.queries(d2 >= 1, 6, seed=11)
+    d2g = torch.from_numpy(d2).cuda()
+    for q in range(6):
+        ref = oracle.astar(d2, s[q], g[q], want_g=True)
+        gf, cost, status = ctx.astar_gfield(d2g, s[q], g[q])
+        assert status == ref["status"] and cost == ref["cost"]
+        assert np.array_equal(gf, ref["g"])
+    # no path: g* over the whole component
+    occ = np.zeros((32, 48), np.uint8); occ[:, 20] = 1
+    d2 = oracle.edt(occ)
+    ref = oracle.astar(d2, 0, 47, want_g=True)
+    gf, cost, status = ctx.astar_gfield(torch.from_numpy(d2).cuda(), 0, 47)
+    assert status == 1 and cost == -1 and np.array_equal(gf, ref["g"])
+
+
+def test_astar_truncated_and_lmax(ctx, oracle):
+    occ = np.zeros((3, 200), np.uint8)
+    d2 = np.full((3, 200), 9, np.int32); d2[0] = 0; d2[2] = 0   # corridor
+    s = np.array([200], np.int32); g = np.array([399], np.int32)
+    ref = oracle.astar_batch(d2, s, g, Lmax=50)
+    out = _run(ctx, d2, s, g, Lmax=50)
+    assert out["status"][0] == 3 == ref["status"][0] and out["len"][0] == 200 == ref["len"][0]
+    out = _run(ctx, d2, s, g, Lmax=200)
+    assert out["status"][0] == 0 and np.array_equal(out["path"][0], np.arange(200, 400))
+
+
+def test_astar_1024_bench_config(ctx, oracle):
+    """BASELINE configs[1] at full size on all three synthetic maps (first 96 queries vs the oracle)."""
+    from sea_current_amd import synth
+    for occ in (synth.salt_grid(1024, 1024, 0.05), synth.block_grid(1024, 1024, 0.2)):
+        d2 = oracle.edt(occ)
+        s, g = synth.queries(d2 >= 1, 96)
+        ref = oracle.astar_batch(d2, s, g, Lmax=4096, nthreads=8)
+        _compare(_run(ctx, d2, s, g, Lmax=4096), ref, 96)
+
+
+def test_astar_host_entry_point(ctx, oracle):
+    from sea_current_amd import synth
+    occ = synth.salt_grid(96, 96, 0.2, seed=8)
+    d2 = oracle.edt(occ)
+    s, g = synth.queries(d2 >= 1, 20, seed=8)
+    ref = oracle.astar_batch(d2, s, g, Lmax=512)
+    _compare(ctx.astar_batch_host(d2, s, g, Lmax=512), ref, 20)

@@ -1,0 +1,83 @@
+"""GPU parity: HIP EDT (through the C ABI) vs the CPU oracle, bit-exact int32."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import sea_current_amd as sc
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    c = sc.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu_edt(ctx, occ):
+    import torch
+    d = ctx.edt(torch.from_numpy(np.ascontiguousarray(occ)).cuda())
+    torch.cuda.synchronize()
+    return d.cpu().numpy()
+
+
+@pytest.mark.parametrize("W,H,p", [(1, 1, 0.5), (5, 3, 0.4), (16, 16, 0.1), (64, 64, 0.2), (33, 65, 0.05),
+                                   (100, 37, 0.02), (256, 256, 0.05), (250, 130, 0.3), (1024, 96, 0.001)])
+def test_edt_matches_oracle_random(ctx, oracle, W, H, p):
+    rng = np.random.default_rng(W * 7919 + H)
+    occ = (rng.random((H, W)) < p).astype(np.uint8) * rng.integers(1, 256, (H, W)).astype(np.uint8)
+    assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+
+
+def test_edt_edge_cases(ctx, oracle):
+    import sea_current_amd as sc
+    assert np.all(_gpu_edt(ctx, np.zeros((70, 40), np.uint8)) == sc.EDT_INF)      # empty grid
+    assert np.all(_gpu_edt(ctx, np.ones((70, 40), np.uint8)) == 0)                # full grid
+    occ = np.zeros((200, 300), np.uint8); occ[199, 0] = 7                        # one far corner obstacle
+    assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+    occ = np.zeros((1, 2000), np.uint8); occ[0, 1999] = 1                        # single row
+    assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+    occ = np.zeros((2000, 1), np.uint8); occ[3, 0] = 1                           # single column
+    assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+
+
+def test_edt_batch_and_blocks(ctx, oracle):
+    import torch
+    from sea_current_amd import synth
+    grids = np.stack([synth.block_grid(192, 160, 0.2, seed=s, smin=3, smax=30) for s in range(5)]
+                     + [synth.salt_grid(192, 160, 0.05, seed=9)])
+    d = ctx.edt(torch.from_numpy(grids).cuda()).cpu().numpy()
+    for i in range(grids.shape[0]):
+        assert np.array_equal(d[i], oracle.edt(grids[i])), i
+
+
+def test_edt_1024_bench_grids(ctx, oracle):
+    from sea_current_amd import synth
+    for occ in (synth.salt_grid(1024, 1024, 0.05), synth.salt_grid(1024, 1024, 0.20), synth.block_grid(1024, 1024, 0.2)):
+        assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+
+
+def test_edt_host_entry_point(ctx, oracle):
+    from sea_current_amd import synth
+    occ = synth.salt_grid(130, 70, 0.1, seed=4)
+    assert np.array_equal(ctx.edt_host(occ), oracle.edt(occ))
+
+
+def test_edt_4096_properties(ctx):
+    """Full-size check through size-independent properties: d2 == 0 exactly on obstacles,
+    1-Lipschitz in distance (|sqrt d2| differs by <= 1 between 4-neighbours), and agreement with
+    the oracle on random row windows is covered at 1024^2; here we also spot-check cells by brute force."""
+    import torch
+    from sea_current_amd import synth
+    occ = synth.salt_grid(4096, 4096, 0.01, seed=2)
+    d2 = _gpu_edt(ctx, occ)
+    assert np.array_equal(d2 == 0, occ != 0)
+    d = np.sqrt(d2.astype(np.float64))
+    assert np.abs(np.diff(d, axis=0)).max() <= 1 + 1e-9 and np.abs(np.diff(d, axis=1)).max() <= 1 + 1e-9
+    ys, xs = np.nonzero(occ)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        y, x = rng.integers(0, 4096, 2)
+        m = (np.abs(ys - y) <= 64) & (np.abs(xs - x) <= 64)
+        assert d2[y, x] == ((ys[m] - y) ** 2 + (xs[m] - x) ** 2).min()
