@@ -25,6 +25,7 @@
 // below 65535 is exact; a row with a pixel still at 65535 (d2 >= 65535: a very sparse grid) is redone
 // with 32-bit registers.  Rows are contiguous in HBM: occupancy reads and d2 writes are coalesced.
 #include "sc_internal.h"
+#include <stdlib.h>
 
 #define EDT_G_INF 0x7FFF                       // "no obstacle in this column"
 #define EDT_F_INF (EDT_G_INF * EDT_G_INF)      // > any real d2 for dims <= 8192
@@ -34,53 +35,50 @@ __device__ __forceinline__ uint32_t nonzero_bytes_hi(uint32_t v) {
     return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
-// One thread = 4*D columns of one band (D dwords per row); W % (4*D) == 0, rows 4*D-byte aligned.
-template <int D>
+// Fast path (W % 16 == 0): block = 64 column groups x 4 row groups of ONE band.  Thread (xg, rg)
+// loads rows 8 rg .. 8 rg + 7 of 16 adjacent columns (8 independent 16-byte loads, issued back to
+// back: the block's requests are one contiguous 32 KiB burst, which keeps HBM row-buffer locality --
+// one thread walking all 32 rows gives 2048 concurrent 1-KiB streams 32 KiB apart and reads at
+// under half the rate), reduces them to 8 row bits per column, and the block transposes through
+// LDS so that every thread assembles and stores the 32-bit words of 4 adjacent columns.
 __global__ void __launch_bounds__(256)
-edt_colbits_kernel(const uint8_t* __restrict__ occ, int W, int H, int nb, int batch, uint32_t* __restrict__ colbits) {
-    const int per_row = W / (4 * D);
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)batch * nb * per_row;
-    if (t >= total) return;
-    const int xg = (int)(t % per_row);
-    const int b = (int)((t / per_row) % nb);
-    const int g = (int)(t / ((long long)per_row * nb));
-    const int x0 = xg * 4 * D;
-    const uint8_t* base = occ + ((size_t)g * H + (size_t)b * 32) * W + x0;
-    const int rows = min(32, H - b * 32);
-    uint32_t Q[D][4];
+edt_colbits_kernel(const uint8_t* __restrict__ occ, int W, int H, int nb, uint32_t* __restrict__ colbits) {
+    __shared__ uint4 sq[4][64];
+    const int xg = threadIdx.x, rg = threadIdx.y;
+    const int b = blockIdx.y, g = blockIdx.z;
+    const int x0 = (blockIdx.x * 64 + xg) * 16;
+    uint32_t Q[4] = {0, 0, 0, 0};   // byte k of Q[dd] = rows 8 rg .. 8 rg + 7 of column x0 + 4 dd + k
+    if (x0 < W) {
+        const int row0 = b * 32 + rg * 8;
+        const uint8_t* base = occ + ((size_t)g * H + row0) * W + x0;
+        uint4 v[8];
 #pragma unroll
-    for (int dd = 0; dd < D; ++dd)
+        for (int i = 0; i < 8; ++i)
+            v[i] = row0 + i < H ? *reinterpret_cast<const uint4*>(base + (size_t)i * W) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Q[dd][j] = 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        uint32_t v[D];
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) v[dd] = 0;
-        if (i < rows) {
-            if constexpr (D == 4) {
-                uint4 q = *reinterpret_cast<const uint4*>(base + (size_t)i * W);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
-                v[0] = *reinterpret_cast<const uint32_t*>(base + (size_t)i * W);
-            }
-        }
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-            uint32_t m = nonzero_bytes_hi(v[dd]);  // byte k bit 7 = column k occupied in row i
-            Q[dd][i >> 3] |= (m >> 7) << (i & 7);  // byte k of Q[.][j] = rows 8j..8j+7 of column k
+        for (int i = 0; i < 8; ++i) {
+            Q[0] |= (nonzero_bytes_hi(v[i].x) >> 7) << i;
+            Q[1] |= (nonzero_bytes_hi(v[i].y) >> 7) << i;
+            Q[2] |= (nonzero_bytes_hi(v[i].z) >> 7) << i;
+            Q[3] |= (nonzero_bytes_hi(v[i].w) >> 7) << i;
         }
     }
-    uint32_t* out = colbits + ((size_t)g * nb + b) * W + x0;
+    sq[rg][xg] = make_uint4(Q[0], Q[1], Q[2], Q[3]);
+    __syncthreads();
+    // thread t assembles columns 4 t .. 4 t + 3 of the block: dword (t % 4) of column group t / 4
+    const int t = rg * 64 + xg;
+    const int xo = blockIdx.x * 1024 + 4 * t;
+    if (xo < W) {
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sq[0][0]);
+        uint32_t q[4];
 #pragma unroll
-    for (int dd = 0; dd < D; ++dd) {
+        for (int r = 0; r < 4; ++r) q[r] = sw[(r * 64 + t / 4) * 4 + (t & 3)];
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            w[k] = ((Q[dd][0] >> (8 * k)) & 0xFF) | (((Q[dd][1] >> (8 * k)) & 0xFF) << 8) |
-                   (((Q[dd][2] >> (8 * k)) & 0xFF) << 16) | (((Q[dd][3] >> (8 * k)) & 0xFF) << 24);
-        *reinterpret_cast<uint4*>(out + 4 * dd) = make_uint4(w[0], w[1], w[2], w[3]);
+            w[k] = ((q[0] >> (8 * k)) & 0xFF) | (((q[1] >> (8 * k)) & 0xFF) << 8) |
+                   (((q[2] >> (8 * k)) & 0xFF) << 16) | (((q[3] >> (8 * k)) & 0xFF) << 24);
+        *reinterpret_cast<uint4*>(colbits + ((size_t)g * nb + b) * W + xo) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -232,11 +230,10 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
                             if (j + HP < nvalid) m = max(m, P[j] >> 16);
                         }
                     }
+                    // still "no obstacle" (d2 >= 65535) somewhere after 256 columns: 32-bit path
+                    if (it == 256 && __ballot(m == 0xFFFFu) != 0) { saturated = true; break; }
                     const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
                     if (__ballot(m > thr) == 0) break;
-                    // Still "no obstacle" somewhere after 64 columns: a sparse row.  Packed values
-                    // cannot reach it before iteration 256; go to the 32-bit path now.
-                    if ((it == 64 || it == 256) && __ballot(m == 0xFFFFu) != 0) { saturated = true; break; }
                 }
             }
             if (!saturated) {
@@ -342,6 +339,251 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
     }
 }
 
+// ---- edt_band_g8_kernel: the W <= 1024 fast path -------------------------------------------------
+// Same cascade, leaner set-up.  Phase 1 turns the band's column words into ALL 32 x W vertical
+// distances with a packed-u16 recurrence (two columns per VGPR:  gu_i = bit_i ? 0 : gu_{i-1} + 1
+// top-down, gd bottom-up, g = min(gu, gd, 255)), ~5 VALU ops per pixel instead of ~16 for the
+// closed form, and stores them as bytes g8[row][x] in LDS (32 KiB at W = 1024).  A row is then one
+// 16-byte LDS read per lane plus perm + pk_mul per pixel pair.  255 stands for ">= 255", so a packed
+// result is trusted only below 255^2 = 65025; rows that end above it (very sparse grids) are redone
+// by the 32-bit cascade with exact distances recomputed from the column words in global memory.
+__device__ __noinline__ uint32_t edt_gdist_global(const uint32_t* cb, int W, int nb, int b, int x, int i) {
+    const uint32_t w = cb[(size_t)b * W + x];
+    const uint32_t wl = w >> i, wh = w << (31 - i);
+    if (wl & 1u) return 0;
+    uint32_t gg = EDT_G_INF;
+    if (wl) gg = (uint32_t)(__ffs((int)wl) - 1);
+    else
+        for (int bb = b + 1; bb < nb; ++bb) {
+            const uint32_t ww = cb[(size_t)bb * W + x];
+            if (ww) { gg = (uint32_t)((bb - b) * 32 + (__ffs((int)ww) - 1) - i); break; }
+        }
+    if (wh) gg = min(gg, (uint32_t)__clz((int)wh));
+    else
+        for (int bb = b - 1; bb >= 0; --bb) {
+            const uint32_t ww = cb[(size_t)bb * W + x];
+            if (ww) { gg = min(gg, (uint32_t)((b - bb) * 32 + i - (31 - __clz((int)ww)))); break; }
+        }
+    return min(gg, (uint32_t)EDT_G_INF);
+}
+
+template <int PPL, bool FULL>
+__global__ void __launch_bounds__(512)
+edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
+    static_assert(PPL == 8 || PPL == 16, "g8 path: 8 or 16 pixels per lane");
+    constexpr int WAVES = 8;
+    constexpr int HP = PPL / 2;
+    constexpr int WP = 64 * PPL;
+    constexpr int TRN = 64 * (HP + 1);             // packed transpose buffer, dwords per wave
+    constexpr uint32_t TRUST = 255u * 255u;        // packed values below this are exact
+    extern __shared__ uint32_t smem[];
+    uint8_t* g8 = reinterpret_cast<uint8_t*>(smem);            // [32][WP]
+    uint32_t* trs = smem + 32 * WP / 4;                        // [WAVES][TRN]
+    const int b = blockIdx.x % nb, g = blockIdx.x / nb;
+    const uint32_t* cb = colbits + (size_t)g * nb * W;
+
+    // ---- phase 1: two adjacent columns per thread -> 32 rows of 2 distance bytes ----
+    for (int q = threadIdx.x; q < WP / 2; q += WAVES * 64) {
+        uint32_t nw[2];
+        int up[2], dn[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int x = 2 * q + c;
+            uint32_t w = 0;
+            up[c] = EDT_G_INF; dn[c] = EDT_G_INF;
+            if (x < W) {
+                w = cb[(size_t)b * W + x];
+                for (int base = b - 1; base >= 0 && up[c] == EDT_G_INF; base -= 4) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ww[t] = base - t >= 0 ? cb[(size_t)(base - t) * W + x] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (up[c] == EDT_G_INF && ww[t]) up[c] = (b - (base - t)) * 32 - (31 - __clz((int)ww[t]));
+                }
+                for (int base = b + 1; base < nb && dn[c] == EDT_G_INF; base += 4) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ww[t] = base + t < nb ? cb[(size_t)(base + t) * W + x] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (dn[c] == EDT_G_INF && ww[t]) dn[c] = ((base + t) - b) * 32 + (__ffs((int)ww[t]) - 1) - 31;
+                }
+            }
+            nw[c] = ~w;
+        }
+        // top-down: gu = rows to the nearest obstacle at or above; stored clamped at 255
+        uint32_t GU[32];
+        uint32_t gu = (uint32_t)(up[0] - 1) | ((uint32_t)(up[1] - 1) << 16);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            // 0xFFFF per half whose cell is free in row i
+            const uint32_t keep = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)nw[1], i, 1),
+                                                        (uint32_t)__builtin_amdgcn_sbfe((int)nw[0], i, 1), 0x05040100u);
+            gu = pk_add_sat(gu, 0x00010001u) & keep;
+            GU[i] = pk_min(gu, 0x00FF00FFu);
+        }
+        // bottom-up: gd restarts at 0 wherever gu == 0 (an obstacle); values past 255 may be clipped
+        // at >= 256 because only min(g, 255) is kept
+        uint32_t gd = (uint32_t)(dn[0] - 1) | ((uint32_t)(dn[1] - 1) << 16);
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            const uint32_t cap = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, GU[i]) << (us2_t)8);
+            gd = pk_min(pk_add_sat(gd, 0x00010001u), cap);
+            const uint32_t gg = pk_min(GU[i], gd);
+            *reinterpret_cast<uint16_t*>(g8 + (size_t)i * WP + 2 * q) = (uint16_t)((gg & 0xFFu) | ((gg >> 8) & 0xFF00u));
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* tr = trs + (size_t)wave * TRN;
+    const int y0 = b * 32;
+    const int nrows = min(32, H - y0);
+    const int nvalid = W - PPL * lane;
+    for (int i = wave; i < nrows; i += WAVES) {
+        int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
+        uint32_t P[HP];
+        {
+            uint32_t dw[PPL / 4];
+            if constexpr (PPL == 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(g8 + (size_t)i * WP + 16 * lane);
+                dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+            } else {
+                const uint2 v = *reinterpret_cast<const uint2*>(g8 + (size_t)i * WP + 8 * lane);
+                dw[0] = v.x; dw[1] = v.y;
+            }
+#pragma unroll
+            for (int j = 0; j < HP; ++j) {
+                // (byte j) | (byte j + HP) << 16, then square both halves
+                const uint32_t sel = 0x0C000C00u | (uint32_t)(j % 4) | ((uint32_t)(4 + j % 4) << 16);
+                const uint32_t t = __builtin_amdgcn_perm(dw[(j + HP) / 4], dw[j / 4], sel);
+                P[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, t) * __builtin_bit_cast(us2_t, t));
+            }
+        }
+        bool saturated = false;
+        for (int it = 1; it <= 255; ++it) {
+            const uint32_t c = (uint32_t)(2 * it - 1) * 0x00010001u;
+            const uint32_t T = P[HP - 1], S = P[0];
+            const uint32_t below = from_lane_below(T, 0xFFFFFFFFu);
+            const uint32_t above = from_lane_above(S, 0xFFFFFFFFu);
+            const uint32_t L0 = __builtin_amdgcn_alignbit(T, below, 16);
+            const uint32_t RL = __builtin_amdgcn_alignbit(above, S, 16);
+            uint32_t prev = L0;
+#pragma unroll
+            for (int j = 0; j < HP; ++j) {
+                const uint32_t cur = P[j];
+                const uint32_t nxt = j < HP - 1 ? P[j + 1] : RL;
+                P[j] = pk_min(cur, pk_add_sat(pk_min(prev, nxt), c));
+                prev = cur;
+            }
+            if ((it & 1) == 0 && (it <= 12 || (it & 3) == 0)) {
+                uint32_t m;
+                if (FULL) {
+                    m = P[0];
+#pragma unroll
+                    for (int j = 1; j < HP; ++j) m = pk_max(m, P[j]);
+                    m = max(m & 0xFFFFu, m >> 16);
+                } else {
+                    m = 0;
+#pragma unroll
+                    for (int j = 0; j < HP; ++j) {
+                        if (j < nvalid) m = max(m, P[j] & 0xFFFFu);
+                        if (j + HP < nvalid) m = max(m, P[j] >> 16);
+                    }
+                }
+                const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
+                if (__ballot(m > thr) == 0) break;
+                if (it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
+            }
+        }
+        if (!saturated) {
+            // packed transpose: lane writes its HP packed registers, reads back u16 halves so that
+            // each lane then holds 4 consecutive pixels for one 16-byte store
+#pragma unroll
+            for (int j = 0; j < HP; ++j) tr[(HP + 1) * lane + j] = P[j];
+            wave_lds_sync();
+            const uint16_t* trh = reinterpret_cast<const uint16_t*>(tr);
+#pragma unroll
+            for (int k = 0; k < PPL / 4; ++k) {
+                const int x = 4 * (64 * k + lane);
+                const int l2 = x / PPL, j2 = x % PPL;                    // owner lane, pixel index there
+                const int hidx = 2 * ((HP + 1) * l2 + (j2 % HP)) + (j2 >= HP ? 1 : 0);
+                int4 v = make_int4(trh[hidx], trh[hidx + 2], trh[hidx + 4], trh[hidx + 6]);
+                if (FULL || x + 3 < W) {
+                    if (FULL || (((uintptr_t)(out + x)) & 15) == 0) *reinterpret_cast<int4*>(out + x) = v;
+                    else { out[x] = v.x; out[x + 1] = v.y; out[x + 2] = v.z; out[x + 3] = v.w; }
+                } else {
+                    if (x < W) out[x] = v.x;
+                    if (x + 1 < W) out[x + 1] = v.y;
+                    if (x + 2 < W) out[x + 2] = v.z;
+                }
+            }
+            wave_lds_sync();
+        } else {
+            // ---- 32-bit cascade with exact distances (very sparse rows) ----
+            uint32_t V[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int x = PPL * lane + j;
+                uint32_t gg = EDT_G_INF;
+                if (x < W) gg = edt_gdist_global(cb, W, nb, b, x, i);
+                V[j] = gg * gg;
+            }
+            for (int it = 1; it < WP; ++it) {
+                const uint32_t c = (uint32_t)(2 * it - 1);
+                const uint32_t below = from_lane_below(V[PPL - 1], (uint32_t)EDT_F_INF);
+                const uint32_t above = from_lane_above(V[0], (uint32_t)EDT_F_INF);
+                uint32_t prev = below;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const uint32_t cur = V[j];
+                    const uint32_t nxt = j < PPL - 1 ? V[j + 1] : above;
+                    V[j] = min(cur, min(prev, nxt) + c);
+                    prev = cur;
+                }
+                if ((it & 7) == 0) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j)
+                        if (FULL || j < nvalid) m = max(m, V[j]);
+                    const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
+                    if (__ballot(m > thr && (m < (uint32_t)EDT_F_INF || it + 1 < W)) == 0) break;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int x = PPL * lane + j;
+                if (x < W) out[x] = V[j] >= (uint32_t)EDT_F_INF ? INT32_MAX : (int)V[j];
+            }
+        }
+    }
+}
+
+template <int PPL, bool FULL>
+static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+    constexpr int WP = 64 * PPL;
+    const size_t lds = (size_t)32 * WP + (size_t)8 * 64 * (PPL / 2 + 1) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_g8_kernel<PPL, FULL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int tk = sc_time_begin(ctx, SC_K_EDT_BAND);
+    hipLaunchKernelGGL((edt_band_g8_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream,
+                       colbits, W, H, nb, d2);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+template <int PPL>
+static int launch_band_g8_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+    return W == 64 * PPL ? launch_band_g8<PPL, true>(ctx, colbits, W, H, nb, batch, d2)
+                         : launch_band_g8<PPL, false>(ctx, colbits, W, H, nb, batch, d2);
+}
+
 template <int PPL, bool FULL>
 static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     constexpr int G = PPL < 16 ? PPL : 16;
@@ -375,18 +617,13 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
     uint32_t* colbits = (uint32_t*)ctx->colbits.p;
     if (batch > 65535 || nb > 65535) return SC_ERR_INVALID;
 
+    static const char* only = getenv("SC_EDT_ONLY");  // debug/profiling: run a single kernel of the pair
+    const bool skip_colbits = only && only[0] == 'b', skip_band = only && only[0] == 'c';
     int tk = sc_time_begin(ctx, SC_K_EDT_COLBITS);
-#ifndef EDT_COLBITS_D
-#define EDT_COLBITS_D 4
-#endif
-    if (EDT_COLBITS_D == 4 && W % 16 == 0 && ((uintptr_t)occ & 15) == 0) {
-        const long long total = (long long)batch * nb * (W / 16);
-        hipLaunchKernelGGL(edt_colbits_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           occ, W, H, nb, batch, colbits);
-    } else if (W % 4 == 0 && ((uintptr_t)occ & 3) == 0) {
-        const long long total = (long long)batch * nb * (W / 4);
-        hipLaunchKernelGGL(edt_colbits_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           occ, W, H, nb, batch, colbits);
+    if (skip_colbits) {
+    } else if (W % 16 == 0 && ((uintptr_t)occ & 15) == 0) {
+        hipLaunchKernelGGL(edt_colbits_kernel, dim3((W + 1023) / 1024, nb, batch), dim3(64, 4), 0, ctx->stream,
+                           occ, W, H, nb, colbits);
     } else {
         dim3 grid((W + 255) / 256, nb, batch);
         hipLaunchKernelGGL(edt_colbits_generic_kernel, grid, dim3(256), 0, ctx->stream, occ, W, H, nb, colbits);
@@ -394,9 +631,14 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
 
+    if (skip_band) return SC_OK;
     // pixels per lane: smallest power of two with 64 * PPL >= W
     if (W <= 128) return launch_band_ppl<2>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 256) return launch_band_ppl<4>(ctx, colbits, W, H, nb, batch, d2);
+#ifndef EDT_NO_G8
+    if (W > 256 && W <= 512) return launch_band_g8_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
+    if (W > 512 && W <= 1024) return launch_band_g8_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
+#endif
     if (W <= 512) return launch_band_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 1024) return launch_band_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 2048) return launch_band_ppl<32>(ctx, colbits, W, H, nb, batch, d2);

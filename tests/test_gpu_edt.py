@@ -40,6 +40,16 @@ def test_edt_edge_cases(ctx, oracle):
     assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
     occ = np.zeros((2000, 1), np.uint8); occ[3, 0] = 1                           # single column
     assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
+    # sparse grids on every kernel variant (W = 1024 full-width fast path, ragged W, wide W):
+    # distances beyond 255 force the 32-bit fallback rows
+    for (H, W) in ((40, 1024), (70, 600), (300, 400), (40, 2048), (33, 3000)):
+        assert np.all(_gpu_edt(ctx, np.zeros((H, W), np.uint8)) == sc.EDT_INF), (H, W)
+        occ = np.zeros((H, W), np.uint8); occ[H // 3, W - 7] = 1
+        assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ)), (H, W)
+        occ[H - 1, 2] = 1; occ[0, W // 2] = 9
+        assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ)), (H, W)
+    occ = np.zeros((700, 1024), np.uint8); occ[350, 500:520] = 1                 # vertical distances > 255
+    assert np.array_equal(_gpu_edt(ctx, occ), oracle.edt(occ))
 
 
 def test_edt_batch_and_blocks(ctx, oracle):
