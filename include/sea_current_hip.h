@@ -122,6 +122,9 @@ int sc_astar_batch_host(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2
                         int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
 /* Node expansions of the last sc_astar_batch call on this context (synchronises). */
 int sc_astar_last_expansions(sc_ctx* ctx, int64_t* expansions);
+/* Debug: per-query {expansions[Q], then (sub-iterations, kilo-cycles)[Q][2]} of the last
+ * sc_astar_batch (the latter only when the environment has SC_ASTAR_DEBUG=1). */
+int sc_astar_debug_stats(sc_ctx* ctx, int32_t* out3, int Q);
 /* Debug/parity: canonical g field (uint32 [H][W], 0xFFFFFFFF = unreached) of ONE query. */
 int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
                     int32_t start, int32_t goal, uint32_t* gfield, int32_t* cost, int32_t* status);

@@ -4,24 +4,38 @@
 // optional waypoint list.  Semantics (costs 10/14, octile heuristic, no corner cutting, canonical
 // g field and parent rule) are written in oracle/sc_oracle.h; results are bit-exact against it.
 //
-// Why a bucket queue: with integer costs and a consistent heuristic every open node has
-// f in [fmin, fmin + 28] (a successor's f exceeds its parent's by at most 2*14), so the open list
-// is 32 circular buckets indexed by f & 31 -- no heap, no comparisons.  Every node in the fmin
-// bucket already has its optimal g, so the whole bucket is expanded in parallel, 64 nodes per
-// step.  Successors are relaxed with atomicMin on the query's private g array (exactly one lane
-// sees old > new, so each (node, g) is queued once) and appended to their buckets by wavefront
-// ballot compaction: lanes that improved a node with the same f' take consecutive slots
-// (popcount of the ballot below the lane); the ring tails live in LDS.  No inter-wave
-// communication exists: a query's g array, buckets and counters are private to its wave.
+// Open list = bucket queue.  With integer costs and a consistent heuristic every open node has
+// f in [fmin, fmin + 28] (a successor's f exceeds its parent's by at most 2*14), so the open list is
+// 32 circular buckets indexed by f & 31 -- no heap, no comparisons.  Every node in the fmin bucket
+// already has its optimal g, so the whole bucket is expanded in parallel, 64 nodes per step.
+// Successors are relaxed with a returning atomicMin on the query's private g array (exactly one lane
+// sees old > new, so each (node, g) is queued exactly once) and appended to their bucket by
+// wavefront-ballot compaction: lanes that improved a node with the same f' take consecutive slots
+// (popcount of the ballot below the lane).  No inter-wave communication exists: a query's g array,
+// buckets and counters are private to its wave.
+//
+// Latency is what bounds a query (the kernel ends with its slowest query), so the critical path of
+// a step is kept to ONE memory round trip:
+//   - successors with f' == f (the long equal-f chains along a corridor) go to a ring in LDS, not to
+//     HBM.  Entries of that ring can never be stale (any later improvement would have f < fmin), and
+//     their g is simply f - h: no load is needed to validate them;
+//   - the move mask of every successor is fetched together with the atomics and stored with the
+//     entry, so the next step starts straight at its atomics.
+// Entries that come back from the HBM buckets (f' > f at insertion time) are validated against g.
+//
+// g values carry a descending epoch tag in their top bits: a slot left over from an earlier launch
+// compares greater than anything written now, so atomicMin treats it as "unset" and the per-batch
+// memset of the g arrays (4 MiB per query at 1024^2) disappears.
 //
 // The search runs until the f = C* bucket is exhausted (not merely until the goal is popped), which
 // makes the final g field -- and therefore the parent chain extracted from it -- independent of the
 // expansion order.
 #include "sc_internal.h"
+#include <stdlib.h>
 
 #define NBUCKET 32
-#define G_UNSET 0xFFFFFFFFu
 #define Q_OVERFLOW 100  // internal: bucket ring overflow, retried by the host with a larger ring
+#define CQ 2048         // LDS ring entries for the current-f queue (power of two)
 
 struct astar_args {
     const uint8_t* moves;
@@ -37,11 +51,14 @@ struct astar_args {
     int32_t* len;
     int32_t* cost;
     int32_t* status;
-    uint32_t* g;        // [slots][cells]
+    uint32_t* g;        // [slots][cells], epoch-tagged
     uint32_t* buckets;  // [slots][NBUCKET][cap]
     int cap;            // power of two
     int32_t* expanded;  // [Q]
+    int32_t* dbg;       // [Q][2] sub-iterations, kilo-cycles (may be null)
     const int32_t* redo;  // optional: only run queries whose status == Q_OVERFLOW
+    uint32_t epoch_tag;   // epoch << shift
+    uint32_t gmask;       // (1 << shift) - 1, or 0xFFFFFFFF when epochs are off
 };
 
 __device__ __forceinline__ int octile(int x, int y, int gx, int gy) {
@@ -55,10 +72,14 @@ __device__ __forceinline__ uint32_t g_load(const uint32_t* p) {
 }
 
 __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
-    __shared__ int s_head[NBUCKET];
-    __shared__ int s_tail[NBUCKET];
-    volatile int* head = s_head;
-    volatile int* tail = s_tail;
+    // LDS ring of the current f level (indexed directly so that the accesses stay ds_* instructions)
+    __shared__ uint32_t qxy[CQ];
+    __shared__ uint8_t qmv[CQ];
+    // head/tail of the 32 HBM bucket rings live in two VGPRs: lane i holds bucket i
+    // (read with v_readlane, updated with a lane-select: no memory traffic on the critical path)
+    int vhead = 0, vtail = 0;
+#define HEAD(bb) __builtin_amdgcn_readlane(vhead, (bb))
+#define TAIL(bb) __builtin_amdgcn_readlane(vtail, (bb))
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     const int q = a.q0 + slot;
@@ -67,9 +88,15 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     const size_t cells = (size_t)W * H;
     const int s = a.start[q], t = a.goal[q];
     int32_t* path = a.path + (size_t)q * a.Lmax;
+    const uint32_t etag = a.epoch_tag, gmask = a.gmask;
 
+    int dbg_iter = 0;
+    unsigned long long dbg_t0 = 0;
     auto finish = [&](int st, int ln, int cs, int ex) {
-        if (lane == 0) { a.status[q] = st; a.len[q] = ln; a.cost[q] = cs; a.expanded[q] = ex; }
+        if (lane == 0) {
+            a.status[q] = st; a.len[q] = ln; a.cost[q] = cs; a.expanded[q] = ex;
+            if (a.dbg) { a.dbg[2 * q] = dbg_iter; a.dbg[2 * q + 1] = (int)((__builtin_amdgcn_s_memtime() - dbg_t0) >> 10); }
+        }
     };
     if (s < 0 || t < 0 || (size_t)s >= cells || (size_t)t >= cells || a.d2[s] < a.rmin || a.d2[t] < a.rmin) {
         finish(SC_Q_BAD_ENDPOINT, 0, -1, 0);
@@ -88,85 +115,128 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     const int ddx[8] = {1, -1, 0, 0, 1, -1, 1, -1};
     const int ddy[8] = {0, 0, 1, -1, 1, 1, -1, -1};
 
-    if (lane < NBUCKET) { head[lane] = 0; tail[lane] = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int fcur = octile(sx, sy, gx, gy);
     if (lane == 0) {
-        __hip_atomic_store(&g[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bk[(size_t)(fcur & 31) * cap] = (uint32_t)(sy << 16 | sx);
-        tail[fcur & 31] = 1;
+        __hip_atomic_store(&g[s], etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
+        qxy[0] = (uint32_t)(sy << 16 | sx);
+        qmv[0] = a.moves[s];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int lh = 0, lt = 1;  // LDS ring of the current f (wave-uniform)
 
     bool found = false, overflow = false;
-    int nexp = 0;
+    int nexp = 0, niter = 0;
+    dbg_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (;;) {
         const int b = fcur & 31;
         uint32_t* bq = bk + (size_t)b * cap;
-        int hd = head[b];
-        // drain the current bucket; same-f successors are appended while we go
+        // drain everything with f == fcur: the LDS ring first, then what earlier levels left in HBM
         for (;;) {
-            const int tl = tail[b];
-            if (hd >= tl) break;
-            for (int base0 = hd; base0 < tl && !overflow; base0 += 64) {
-                const int idx = base0 + lane;
-                const bool act = idx < tl;
-                uint32_t xy = act ? bq[idx & capm] : 0u;
-                const int cx = xy & 0xFFFF, cy = xy >> 16;
-                const int c = cy * W + cx;
-                uint32_t gc = act ? g_load(&g[c]) : 0u;
-                uint32_t mv = act ? a.moves[c] : 0u;
-                const bool valid = act && (int)(gc + octile(cx, cy, gx, gy)) == fcur;  // else stale entry
-                if (!valid) mv = 0;
-                nexp += __popcll(__ballot(valid));
-                if (__ballot(valid && c == t)) found = true;
-                uint32_t old[8];
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    old[d] = 0;
-                    if ((mv >> d) & 1)
-                        old[d] = __hip_atomic_fetch_min(&g[c + off[d]], gc + (d < 4 ? 10u : 14u), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
+            int cx = 0, cy = 0, c = 0;
+            uint32_t gc = 0, mv = 0;
+            bool valid = false;
+            if (lt != lh) {
+                const int n = min(64, lt - lh);
+                if (lane < n) {
+                    const uint32_t xy = qxy[(lh + lane) & (CQ - 1)];
+                    mv = qmv[(lh + lane) & (CQ - 1)];
+                    cx = xy & 0xFFFF; cy = xy >> 16;
+                    c = cy * W + cx;
+                    gc = (uint32_t)(fcur - octile(cx, cy, gx, gy));  // never stale: g = f - h
+                    valid = true;
                 }
+                lh += n;
+            } else {
+                const int hd = HEAD(b), tl = TAIL(b);
+                if (hd == tl) break;
+                const int n = min(64, tl - hd);
+                if (lane < n) {
+                    const uint32_t xy = bq[(hd + lane) & capm];
+                    cx = xy & 0xFFFF; cy = xy >> 16;
+                    c = cy * W + cx;
+                    const uint32_t gv = g_load(&g[c]);
+                    mv = a.moves[c];
+                    gc = gv & gmask;
+                    // stale unless it still carries this launch's tag and the g that put it in this bucket
+                    valid = (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
+                }
+                vhead = lane == b ? hd + n : vhead;
+            }
+            if (!valid) mv = 0;
+            ++niter;
+            nexp += __popcll(__ballot(valid));
+            if (__ballot(valid && c == t)) found = true;
+            // Scattered returning atomics are the scarcest resource of this kernel (one request per
+            // lane, ~20 G/s chip-wide), so neighbours are first filtered with plain L2 loads of g: only
+            // candidates that can still improve (about one in six) go on to the atomicMin, and only
+            // those fetch their move mask.
+            uint32_t old[8], nmv[8];
 #pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    const uint32_t ng = gc + (d < 4 ? 10u : 14u);
-                    const bool imp = ((mv >> d) & 1) && old[d] > ng;
-                    const int nx = cx + ddx[d], ny = cy + ddy[d];
-                    const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;  // in {0,6,8,14,20,28}
-                    unsigned long long rem = __ballot(imp);
-                    while (rem) {
-                        const int leader = __ffsll((long long)rem) - 1;
-                        const int v = __builtin_amdgcn_readlane(df, leader);
-                        const unsigned long long m = __ballot(imp && df == v);
-                        const int bb = (fcur + v) & 31;
-                        const int base = tail[bb];
-                        const int cnt = __popcll(m);
-                        if (base + cnt - head[bb] > cap) overflow = true;
-                        else {
-                            if (imp && df == v)
-                                bk[(size_t)bb * cap + ((base + __popcll(m & lt_mask)) & capm)] = (uint32_t)(ny << 16 | nx);
-                            if (lane == 0) tail[bb] = base + cnt;
-                        }
-                        rem &= ~m;
-                    }
+            for (int d = 0; d < 8; ++d) {
+                old[d] = 0;
+                if ((mv >> d) & 1) old[d] = g_load(&g[c + off[d]]);
+            }
+            uint32_t cand = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                if (((mv >> d) & 1) && old[d] > (etag | (gc + (d < 4 ? 10u : 14u)))) cand |= 1u << d;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                nmv[d] = 0;
+                if ((cand >> d) & 1) {
+                    old[d] = __hip_atomic_fetch_min(&g[c + off[d]], etag | (gc + (d < 4 ? 10u : 14u)), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    nmv[d] = a.moves[c + off[d]];
                 }
             }
+            mv = cand;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t ng = gc + (d < 4 ? 10u : 14u);
+                const bool imp = ((mv >> d) & 1) && old[d] > (etag | ng);
+                const int nx = cx + ddx[d], ny = cy + ddy[d];
+                const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;  // in {0,6,8,14,20,28}
+                unsigned long long rem = __ballot(imp);
+                while (rem) {
+                    const int leader = __ffsll((long long)rem) - 1;
+                    const int v = __builtin_amdgcn_readlane(df, leader);
+                    const bool mine = imp && df == v;
+                    const unsigned long long m = __ballot(mine);
+                    const int cnt = __popcll(m);
+                    const int rank = __popcll(m & lt_mask);
+                    if (v == 0 && lt - lh + cnt <= CQ) {
+                        if (mine) {
+                            qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
+                            qmv[(lt + rank) & (CQ - 1)] = (uint8_t)nmv[d];
+                        }
+                        lt += cnt;
+                    } else {
+                        const int bb = (fcur + v) & 31;
+                        const int base = TAIL(bb);
+                        if (base + cnt - HEAD(bb) > cap) overflow = true;
+                        else {
+                            if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | nx);
+                            vtail = lane == bb ? base + cnt : vtail;
+                        }
+                    }
+                    rem &= ~m;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (overflow) break;
-            hd = tl;
-            if (lane == 0) head[b] = hd;
         }
         if (overflow || found) break;
-        // bucket fcur is empty: advance to the next non-empty one
-        int step = 1;
-        for (; step < NBUCKET; ++step)
-            if (head[(fcur + step) & 31] != tail[(fcur + step) & 31]) break;
-        if (step == NBUCKET) break;  // open list empty: no path
-        fcur += step;
+        // level fcur is exhausted: advance to the next non-empty bucket
+        const uint32_t nonempty = (uint32_t)__ballot(vhead != vtail);   // bit i = bucket i (lanes >= 32 hold 0 == 0)
+        if (nonempty == 0) break;  // open list empty: no path
+        const int r0 = (fcur + 1) & 31;
+        const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
+        fcur += 1 + (__ffs((int)rot) - 1);
     }
 
+    dbg_iter = niter;
     if (overflow) { finish(Q_OVERFLOW, 0, -1, nexp); return; }
     if (!found) { finish(SC_Q_NO_PATH, 0, -1, nexp); return; }
 
@@ -185,7 +255,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                 const int n = ny * W + nx;
                 if ((a.moves[n] >> d) & 1) {
                     const uint32_t gn = g_load(&g[n]);
-                    ok = gn != G_UNSET && gn + (d < 4 ? 10u : 14u) == gc;
+                    ok = gn == (etag | (gc - (d < 4 ? 10u : 14u)));  // tagged and g[n] + w == g[c]
                 }
             }
         }
@@ -213,6 +283,15 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     finish(SC_Q_OK, L, fcur, nexp);
 }
 
+// strip the epoch tags of one slot: canonical g field (0xFFFFFFFF = unreached)
+__global__ void __launch_bounds__(256) gfield_untag_kernel(const uint32_t* g, size_t cells, uint32_t etag, uint32_t gmask, uint32_t* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cells) {
+        const uint32_t v = g[i];
+        out[i] = (v & ~gmask) == etag && (gmask != 0xFFFFFFFFu || v != 0xFFFFFFFFu) ? (v & gmask) : 0xFFFFFFFFu;
+    }
+}
+
 static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, const int32_t* start,
                      const int32_t* goal, int Q, int Lmax, int32_t* path, int32_t* len, int32_t* cost,
                      int32_t* status) {
@@ -222,9 +301,11 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
     if (r != SC_OK) return r;
     r = sc_launch_moves(ctx, d2, W, H, r2, (uint8_t*)ctx->moves.p);
     if (r != SC_OK) return r;
-    r = sc_scratch_reserve(ctx, &ctx->qstats, (size_t)Q * sizeof(int32_t));
+    r = sc_scratch_reserve(ctx, &ctx->qstats, (size_t)Q * 3 * sizeof(int32_t));
     if (r != SC_OK) return r;
     ctx->last_Q = Q;
+    // epoch layout: the g field needs log2(14 * cells) bits
+    int shift = cells * 14 < (1u << 24) ? 24 : cells * 14 < (1u << 28) ? 28 : 32;
 
     int cap = ctx->astar_cap;
     const int32_t* redo = nullptr;
@@ -233,23 +314,40 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
         size_t slots = ctx->astar_slot_budget / per_slot;
         if (slots < 1) slots = 1;
         if (slots > (size_t)Q) slots = Q;
-        r = sc_scratch_reserve(ctx, &ctx->gslots, slots * cells * 4);
+        const size_t g_bytes = slots * cells * 4;
+        if (g_bytes > ctx->gslots.bytes || shift != ctx->astar_shift) ctx->astar_epoch = 0;  // fresh or re-laid-out memory
+        r = sc_scratch_reserve(ctx, &ctx->gslots, g_bytes);
         if (r != SC_OK) return r;
         r = sc_scratch_reserve(ctx, &ctx->buckets, slots * NBUCKET * (size_t)cap * 4);
         if (r != SC_OK) return r;
+        ctx->astar_shift = shift;
         for (int q0 = 0; q0 < Q; q0 += (int)slots) {
             const int nq = (int)((size_t)(Q - q0) < slots ? (size_t)(Q - q0) : slots);
-            SC_HIP(ctx, hipMemsetAsync(ctx->gslots.p, 0xFF, (size_t)nq * cells * 4, ctx->stream));
+            uint32_t etag, gmask;
+            if (shift == 32) {
+                SC_HIP(ctx, hipMemsetAsync(ctx->gslots.p, 0xFF, ctx->gslots.bytes, ctx->stream));
+                etag = 0; gmask = 0xFFFFFFFFu;
+            } else {
+                // epochs count down from (all ones) - 1; 0 is never used so that tag | g != 0xFFFFFFFF is not needed
+                if (ctx->astar_epoch <= 1) {
+                    SC_HIP(ctx, hipMemsetAsync(ctx->gslots.p, 0xFF, ctx->gslots.bytes, ctx->stream));
+                    ctx->astar_epoch = (1u << (32 - shift)) - 1;
+                }
+                ctx->astar_epoch -= 1;
+                etag = ctx->astar_epoch << shift;
+                gmask = (1u << shift) - 1;
+            }
+            ctx->astar_last_tag = etag; ctx->astar_last_mask = gmask;
             astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, q0, nq, Lmax, path, len, cost,
-                         status, (uint32_t*)ctx->gslots.p, (uint32_t*)ctx->buckets.p, cap, (int32_t*)ctx->qstats.p, redo};
+                         status, (uint32_t*)ctx->gslots.p, (uint32_t*)ctx->buckets.p, cap, (int32_t*)ctx->qstats.p,
+                         getenv("SC_ASTAR_DEBUG") ? (int32_t*)ctx->qstats.p + Q : nullptr, redo,
+                         etag, gmask};
             int tk = sc_time_begin(ctx, SC_K_ASTAR);
             hipLaunchKernelGGL(astar_kernel, dim3(nq), dim3(64), 0, ctx->stream, a);
             sc_time_end(ctx, tk);
             SC_HIP(ctx, hipGetLastError());
         }
-        // Ring overflow is rare (cap is generous); detecting it needs the statuses on the host.
-        // Only pay the synchronisation when a previous call on this context ever overflowed or
-        // on the first call with this grid size.
+        // Bucket-ring overflow is rare (cap is generous) but must be seen on the host to retry.
         std::vector<int32_t> st(Q);
         SC_HIP(ctx, hipMemcpyAsync(st.data(), status, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
         SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -301,9 +399,19 @@ extern "C" int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int
     int32_t h[2] = {start, goal};
     SC_HIP(ctx, hipMemcpyAsync(sg, h, 8, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // Lmax = 1: the path is not wanted; a found path reports SC_Q_TRUNCATED, mapped back to OK below
+    // Lmax = 1: the path is not wanted; a found path reports SC_Q_TRUNCATED
     r = astar_run(ctx, d2, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status);
     if (r != SC_OK) return r;
-    SC_HIP(ctx, hipMemcpyAsync(gfield, ctx->gslots.p, cells * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(gfield_untag_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)ctx->gslots.p, cells, ctx->astar_last_tag, ctx->astar_last_mask, gfield);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+// debug: per-query {expansions, sub-iterations, kilo-cycles} of the last batch (needs SC_ASTAR_DEBUG=1)
+extern "C" int sc_astar_debug_stats(sc_ctx* ctx, int32_t* out3, int Q) {
+    if (!ctx || !out3 || Q != ctx->last_Q) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipMemcpyAsync(out3, ctx->qstats.p, (size_t)Q * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;
 }

@@ -36,6 +36,9 @@ struct sc_ctx {
     int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
     int last_Q = 0;
+    uint32_t astar_epoch = 0;       // descending epoch tag of the g slots (0: slots must be cleared)
+    int astar_shift = 0;            // bits of g below the tag
+    uint32_t astar_last_tag = 0, astar_last_mask = 0xFFFFFFFFu;
 };
 
 #define SC_HIP(ctx, call)                                                                  \

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "sc_astar_batch": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_astar_batch_host": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_astar_last_expansions": (_i, [_vp, _i64p]),
+    "sc_astar_debug_stats": (_i, [_vp, _vp, _i]),
     "sc_astar_gfield": (_i, [_vp, _vp, _i, _i, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sc_toppra_hermite_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
@@ -187,6 +188,11 @@ class Context:
         n = C.c_int64(0)
         self._ck(self._l.sc_astar_last_expansions(self._h, C.byref(n)), "sc_astar_last_expansions")
         return n.value
+
+    def astar_debug_stats(self, Q):
+        out = np.zeros(3 * Q, dtype=np.int32)
+        self._ck(self._l.sc_astar_debug_stats(self._h, _ptr(out), Q), "sc_astar_debug_stats")
+        return out[:Q], out[Q:].reshape(Q, 2)
 
     def astar_gfield(self, d2, start, goal, r2=0):
         import torch
