@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 EDT_BYTES_PER_CELL = 5  # read occ 1 B + write d2 4 B
 
 
+FAMILIES = ("salt05", "salt20", "blocks")
+
+
 def make_grid(name, W, H):
     from sea_current_amd import synth
     if name == "salt05":
@@ -54,7 +57,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--map", default="blocks", choices=["salt05", "salt20", "blocks"])
+    ap.add_argument("--map", default="salt20", choices=list(FAMILIES),
+                    help="obstacle family of the headline numbers (the other two are reported under other_maps)")
+    ap.add_argument("--only-main-map", action="store_true")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,29 +85,8 @@ def main():
     W = H = args.size
     Qloc = args.queries
     Qtot = Qloc * world
-    occ_h = make_grid(args.map, W, H)
     ctx = sc.Context(local_rank)
-    occ = torch.from_numpy(occ_h).to(dev)
-    d2 = torch.empty((H, W), dtype=torch.int32, device=dev)
-    ctx.edt(occ, out=d2.view(1, H, W))
-    torch.cuda.synchronize()
-    # queries are drawn from the largest free component (needs the traversable mask once, on the host)
-    trav = d2.cpu().numpy() >= 1
     q0, q1 = shard.rank_range(Qtot, world, rank)
-    s_h, g_h = synth.queries(trav, q1 - q0, first=q0)
-    start = torch.from_numpy(s_h).to(dev)
-    goal = torch.from_numpy(g_h).to(dev)
-    out = dict(path=torch.empty((Qloc, args.lmax), dtype=torch.int32, device=dev),
-               len=torch.empty(Qloc, dtype=torch.int32, device=dev),
-               cost=torch.empty(Qloc, dtype=torch.int32, device=dev),
-               status=torch.empty(Qloc, dtype=torch.int32, device=dev))
-    gathered = shard.alloc_gather(out, world) if world > 1 else None
-
-    def step():
-        ctx.edt(occ, out=d2.view(1, H, W))
-        ctx.astar_batch(d2, start, goal, r2=0, Lmax=args.lmax, out=out)
-        if world > 1:
-            shard.allgather_paths(out, gathered, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -110,48 +94,77 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.set_timing(True)
-    ctx.reset_timing()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    step_kernels = {}
-    for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR)):
-        ms, n = ctx.get_timing(kid)
-        step_kernels[name] = {"ms_per_step": ms / max(args.steps, 1), "launches": n}
-    ctx.set_timing(False)
-    expansions = ctx.astar_last_expansions()
-    st = out["status"].cpu().numpy()
-    ln = out["len"].cpu().numpy()
+    def run_map(family, steps, warmup):
+        """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ all-gather])."""
+        occ_h = make_grid(family, W, H)
+        occ = torch.from_numpy(occ_h).to(dev)
+        d2 = torch.empty((H, W), dtype=torch.int32, device=dev)
+        ctx.edt(occ, out=d2.view(1, H, W))
+        torch.cuda.synchronize()
+        # queries are drawn from the largest free component (needs the traversable mask once, on the host)
+        s_h, g_h = synth.queries(d2.cpu().numpy() >= 1, q1 - q0, first=q0)
+        start = torch.from_numpy(s_h).to(dev)
+        goal = torch.from_numpy(g_h).to(dev)
+        out = dict(path=torch.empty((Qloc, args.lmax), dtype=torch.int32, device=dev),
+                   len=torch.empty(Qloc, dtype=torch.int32, device=dev),
+                   cost=torch.empty(Qloc, dtype=torch.int32, device=dev),
+                   status=torch.empty(Qloc, dtype=torch.int32, device=dev))
+        gathered = shard.alloc_gather(out, world) if world > 1 else None
+
+        def step():
+            ctx.edt(occ, out=d2.view(1, H, W))
+            ctx.astar_batch(d2, start, goal, r2=0, Lmax=args.lmax, out=out)
+            if world > 1:
+                shard.allgather_paths(out, gathered, dist)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        ctx.set_timing(True)
+        ctx.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        step_kernels = {}
+        for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR)):
+            ms, n = ctx.get_timing(kid)
+            step_kernels[name] = {"ms_per_step": ms / max(steps, 1), "launches": n}
+        ctx.set_timing(False)
+        expansions = ctx.astar_last_expansions()
+        st = out["status"].cpu().numpy()
+        ln = out["len"].cpu().numpy()
+        astar_ms = step_kernels["astar"]["ms_per_step"]
+        return dict(value=Qtot * steps / dt, ms_per_step=1e3 * dt / steps, step_kernels=step_kernels,
+                    astar={"expansions_per_step_rank0": expansions,
+                           "expansions_per_s_rank0": expansions / (astar_ms * 1e-3) if astar_ms > 0 else None,
+                           "algorithmic_GBps_rank0": 104 * expansions / (astar_ms * 1e-3) / 1e9 if astar_ms > 0 else None,
+                           "found": int((st == 0).sum()), "no_path": int((st == 1).sum()),
+                           "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
+                    _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st))
+
+    main_run = run_map(args.map, args.steps, args.warmup)
+    others = {} if args.only_main_map else {f: run_map(f, max(2, min(args.steps, 3)), 1) for f in FAMILIES if f != args.map}
+    occ_h, s_h, g_h, out, st = (main_run["_host"][k] for k in ("occ", "s", "g", "out", "st"))
 
     result = None
     if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        value = Qtot * args.steps / dt
-        astar_ms = step_kernels["astar"]["ms_per_step"]
         result = {
-            "metric": "plans/sec (batched start-goal, 1024^2 grid)", "value": value, "unit": "plans/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "metric": "plans/sec (batched start-goal, 1024^2 grid)", "value": main_run["value"], "unit": "plans/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_run["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} random-obstacle grid ({args.map}), EDT + A*, {Qloc} batched queries per GPU"
                                    + (", RCCL all-gather of paths" if world > 1 else ""),
                        "grid": [W, H], "map": args.map, "queries_per_gpu": Qloc, "queries_total": Qtot, "lmax": args.lmax,
                        "parallelism": f"query-sharded x{world}"},
-            "step_kernels": step_kernels,
-            "astar": {"expansions_per_step_rank0": expansions,
-                      "expansions_per_s_rank0": expansions / (astar_ms * 1e-3) if astar_ms > 0 else None,
-                      "algorithmic_GBps_rank0": 104 * expansions / (astar_ms * 1e-3) / 1e9 if astar_ms > 0 else None,
-                      "found": int((st == 0).sum()), "no_path": int((st == 1).sum()),
-                      "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
+            "step_kernels": main_run["step_kernels"], "astar": main_run["astar"],
+            "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"], "astar_ms_per_step": r["step_kernels"]["astar"]["ms_per_step"],
+                               "expansions_per_step_rank0": r["astar"]["expansions_per_step_rank0"]} for f, r in others.items()},
         }
 
     # ---- roofline leg: EDT on a batch of grids (rank 0 only, N = 1 semantics) ----
@@ -198,11 +211,36 @@ def main():
                                          for k, v in legs.items() if k != args.map}
         del d2b
 
+        # ---- TOPP-RA leg (BASELINE configs[2]: 1k plans, 6-DOF, 200 waypoints): reported, not part of `value` ----
+        P, dof, N = 1024, 6, 200
+        pl = synth.toppra_plans(P, dof=dof)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        targs = (tt(pl["p0"]), tt(pl["p1"]), tt(pl["v0"]), tt(pl["v1"]), tt(-pl["vlim"]), tt(pl["vlim"]), tt(-pl["alim"]), tt(pl["alim"]))
+        for _ in range(2):
+            tp = ctx.toppra(*targs, N=N)
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        ctx.reset_timing()
+        for _ in range(10):
+            tp = ctx.toppra(*targs, N=N)
+            smp = ctx.toppra_sample(targs[0], targs[1], targs[2], targs[3], tp["x"], tp["t"], 0.02, 512)
+        torch.cuda.synchronize()
+        ms_t, _ = ctx.get_timing(sc.K_TOPPRA)
+        ms_s, _ = ctx.get_timing(sc.K_TOPPRA_SAMPLE)
+        ctx.set_timing(False)
+        ok_plans = int((tp["status"] == 0).sum())
+        tbytes = 128 * P * (N + 1)  # 128 B per (plan, stage) at dof 6
+        result["toppra"] = {"plans": P, "dof": dof, "stages": N, "ok": ok_plans, "ms_sweep": ms_t / 10, "ms_sample": ms_s / 10,
+                            "plans_per_s": P / ((ms_t + ms_s) / 10 * 1e-3), "algorithmic_GBps": tbytes / (ms_t / 10 * 1e-3) / 1e9,
+                            "hbm_frac": tbytes / (ms_t / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "latency-bound (two dependent 200-stage sweeps per plan), not HBM-bound"}
+
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only, never the measured product
         oracle.build()
-        cores = os.cpu_count() or 1
+        # gpurun boxes give one GPU a 16-core share of the host; never oversubscribe it
+        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         t0 = time.perf_counter()
         d2_ref = oracle.edt(occ_h)
         t_edt = time.perf_counter() - t0

@@ -1,0 +1,445 @@
+// sea_current.hpp -- MI355X-native successor of turtle-robotics/sea-current's single header.
+//
+// Keeps the `turtle::sc` names, argument order and result types of the reference's planning path
+// and velocity-profile path (citations: file:line in the reference's sea_current.hpp), and routes
+// the work to libsea_current_hip.so through the C ABI in include/sea_current_hip.h:
+//
+//   reference                                             here
+//   ---------------------------------------------------   ------------------------------------------
+//   bounding_rect                      :61-83             same members / constructor order
+//   obstacle (polygon, ray casting)    :193-284           same members; rasterised into occupancy_grid
+//   planning_space::is_obstacle        :1274-1280         same signature (polygon test, host)
+//   planning_space::is_free            :1289-1292         same signature
+//   planning_space::cost               :1315-1326         same signature and FLT_MAX convention
+//   planning_space::fast_marching_trees:1339-1407         same signature; grid EDT + batched A* on the GPU
+//   velocity_profile                   :379-386           same members
+//   vel_lim_func                       :1175              same shape
+//   gen_vel_prof<N>                    :1191-1265         same argument order (END before START), GPU TOPP-RA
+//   (new) occupancy_grid, planning_space::plan_batch, gen_vel_prof_batch: the batched entry points
+//
+// Differences that are deliberate: obstacle::closed is initialised (the reference leaves it
+// uninitialised, :197); library code never prints or calls std::exit (SC_ASSERT throws in DEBUG);
+// all functions are `inline` (the reference defines non-inline functions in a header).
+// Not mirrored yet ("next"): bezier_spline, arclength/resample, chebfit, FMT* sampling
+// helpers (halton, sample_free, near), JSON/ZMQ I/O.
+//
+// Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
+// Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
+// There is no CPU fallback: without a gfx950 GPU every planning call throws std::runtime_error.
+#pragma once
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../include/sea_current_hip.h"
+
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define SC_HAVE_EIGEN 1
+#endif
+
+#ifdef DEBUG
+#define SC_ASSERT(cnd, msg)                                                                       \
+    do {                                                                                          \
+        if (!bool(cnd)) throw std::logic_error(std::string("SC_ASSERT failed: ") + #cnd + ": " + (msg)); \
+    } while (0)
+#else
+#define SC_ASSERT(cnd, msg)
+#endif
+
+namespace turtle::sc {
+
+#ifdef SC_HAVE_EIGEN
+using Eigen::Vector2f;
+using Eigen::VectorXf;
+using VectorXd = Eigen::VectorXd;
+template <int N> using VectorNd = Eigen::Matrix<double, N, 1>;
+#else
+// minimal stand-ins with the accessors the API uses
+struct Vector2f {
+    float v[2] = {0, 0};
+    Vector2f() = default;
+    Vector2f(float x, float y) : v{x, y} {}
+    float x() const { return v[0]; }
+    float y() const { return v[1]; }
+    float& x() { return v[0]; }
+    float& y() { return v[1]; }
+    Vector2f operator+(const Vector2f& o) const { return {v[0] + o.v[0], v[1] + o.v[1]}; }
+    Vector2f operator-(const Vector2f& o) const { return {v[0] - o.v[0], v[1] - o.v[1]}; }
+    Vector2f operator*(float s) const { return {v[0] * s, v[1] * s}; }
+    bool operator==(const Vector2f& o) const { return v[0] == o.v[0] && v[1] == o.v[1]; }
+    float norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1]); }
+};
+template <class T> struct VectorX_ {
+    std::vector<T> d;
+    VectorX_() = default;
+    explicit VectorX_(size_t n) : d(n) {}
+    static VectorX_ Zero(size_t n) { return VectorX_(n); }
+    size_t rows() const { return d.size(); }
+    size_t size() const { return d.size(); }
+    T& operator()(size_t i) { return d[i]; }
+    const T& operator()(size_t i) const { return d[i]; }
+    T& operator[](size_t i) { return d[i]; }
+    const T& operator[](size_t i) const { return d[i]; }
+    T* data() { return d.data(); }
+    const T* data() const { return d.data(); }
+};
+using VectorXf = VectorX_<float>;
+using VectorXd = VectorX_<double>;
+template <int N> struct VectorNd {
+    double d[N] = {};
+    VectorNd() = default;
+    VectorNd(std::initializer_list<double> l) { int i = 0; for (double x : l) if (i < N) d[i++] = x; }
+    int rows() const { return N; }
+    double& operator()(int i) { return d[i]; }
+    const double& operator()(int i) const { return d[i]; }
+    double& operator[](int i) { return d[i]; }
+    const double& operator[](int i) const { return d[i]; }
+};
+#endif
+
+// stand-ins for the toppra types that appear in the reference's signatures
+using value_type = double;
+namespace toppra_compat { using Vector = VectorXd; }
+
+// ---- GPU context -------------------------------------------------------------------------------
+class gpu_context {
+public:
+    explicit gpu_context(int device = 0) {
+        int st = sc_ctx_create(device, &h_);
+        if (st != SC_OK)
+            throw std::runtime_error(std::string("sea_current: no usable MI355X context (") + sc_status_string(st) +
+                                     "); there is no CPU fallback");
+    }
+    ~gpu_context() { if (h_) sc_ctx_destroy(h_); }
+    gpu_context(const gpu_context&) = delete;
+    gpu_context& operator=(const gpu_context&) = delete;
+    sc_ctx* get() const { return h_; }
+    void check(int st, const char* what) const {
+        if (st != SC_OK) throw std::runtime_error(std::string(what) + ": " + sc_status_string(st) + ": " + sc_last_error(h_));
+    }
+private:
+    sc_ctx* h_ = nullptr;
+};
+// one context per host thread (contexts are not shared between threads: sea_current_hip.h)
+inline gpu_context& default_context() {
+    thread_local gpu_context ctx(0);
+    return ctx;
+}
+
+// ---- geometry (sea_current.hpp:61-83) -------------------------------------------------------------
+struct bounding_rect {
+    float x_max;
+    float x_min;
+    float y_max;
+    float y_min;
+    bounding_rect(const float x_max, const float x_min, const float y_max, const float y_min)
+        : x_max(x_max), x_min(x_min), y_max(y_max), y_min(y_min) {}
+    inline bool contains(const Vector2f& p) const { return p.x() <= x_max && p.x() >= x_min && p.y() <= y_max && p.y() >= y_min; }
+    inline void enclose_point(const Vector2f& p) {
+        x_max = std::max(x_max, p.x()); x_min = std::min(x_min, p.x());
+        y_max = std::max(y_max, p.y()); y_min = std::min(y_min, p.y());
+    }
+};
+
+inline float pt_dist(const Vector2f& u, const Vector2f& v = {0, 0}) { return std::hypot(v.x() - u.x(), v.y() - u.y()); }
+inline float cross2d(const Vector2f& a, const Vector2f& b) { return a.x() * b.y() - a.y() * b.x(); }
+
+// proper intersection of segments p1p2 and q1q2 (colinear overlap counts as no hit, as in :142-178)
+inline std::tuple<bool, Vector2f> intersects(const Vector2f& p1, const Vector2f& p2, const Vector2f& q1, const Vector2f& q2) {
+    const Vector2f r = p2 - p1, s = q2 - q1, qp = q1 - p1;
+    const float den = cross2d(r, s);
+    if (den == 0.0f) return {false, Vector2f(0, 0)};
+    const float t = cross2d(qp, s) / den, u = cross2d(qp, r) / den;
+    if (t < 0 || t > 1 || u < 0 || u > 1) return {false, Vector2f(0, 0)};
+    return {true, p1 + r * t};
+}
+
+// ---- obstacle (sea_current.hpp:193-284) -----------------------------------------------------------
+struct obstacle {
+    std::vector<std::tuple<Vector2f, Vector2f>> lines;
+    std::vector<Vector2f> vertices;
+    bounding_rect bound_rect = {0, 0, 0, 0};
+    bool closed = true;  // the reference never initialises this member
+    int64_t id = 0;
+
+    obstacle() {}
+    // closed polygon through `vertices` (the last edge returns to the first vertex)
+    obstacle(std::vector<Vector2f> verts) : vertices(std::move(verts)) {
+        if (vertices.empty()) return;
+        bound_rect = {vertices[0].x(), vertices[0].x(), vertices[0].y(), vertices[0].y()};
+        for (size_t i = 0; i < vertices.size(); ++i) {
+            lines.push_back({vertices[i], vertices[(i + 1) % vertices.size()]});
+            bound_rect.enclose_point(vertices[i]);
+        }
+    }
+    // explicit edge list (open or closed shapes)
+    obstacle(std::vector<Vector2f> verts, std::vector<std::tuple<int, int>> edges) : vertices(std::move(verts)) {
+        if (vertices.empty()) return;
+        bound_rect = {vertices[0].x(), vertices[0].x(), vertices[0].y(), vertices[0].y()};
+        for (const auto& e : edges) {
+            SC_ASSERT(std::get<0>(e) < (int)vertices.size() && std::get<1>(e) < (int)vertices.size(), "edge index out of range");
+            lines.push_back({vertices[std::get<0>(e)], vertices[std::get<1>(e)]});
+            bound_rect.enclose_point(vertices[std::get<0>(e)]);
+            bound_rect.enclose_point(vertices[std::get<1>(e)]);
+        }
+    }
+    // even-odd rule on the edge list (closed) / distance-to-edge test (open), after the AABB reject
+    bool contains(const Vector2f& p) const {
+        if (!bound_rect.contains(p)) return false;
+        if (!closed) {
+            for (const auto& [a, b] : lines) {
+                const Vector2f ab = b - a, ap = p - a;
+                const float len = ab.norm();
+                if (len > 0 && std::fabs(cross2d(ab, ap)) / len < 0.01f) return true;
+            }
+            return false;
+        }
+        bool inside = false;
+        for (const auto& [a, b] : lines) {
+            if ((a.y() > p.y()) != (b.y() > p.y())) {
+                const float xi = a.x() + (p.y() - a.y()) * (b.x() - a.x()) / (b.y() - a.y());
+                if (p.x() < xi) inside = !inside;
+            }
+        }
+        return inside;
+    }
+};
+
+// ---- occupancy grid (new): the world model the GPU path works on ----------------------------------
+// Row-major uint8 occupancy over a bounding_rect; cell (ix, iy) covers
+// [x_min + ix*res, x_min + (ix+1)*res) x [y_min + iy*res, ...).  d2 is the exact squared distance (in
+// cells) to the nearest occupied cell, computed on the GPU (sc_edt_u8_i32).
+class occupancy_grid {
+public:
+    int W = 0, H = 0;
+    float resolution = 1.0f;
+    bounding_rect bound_rect = {0, 0, 0, 0};
+    std::vector<uint8_t> occ;
+    std::vector<int32_t> d2;  // filled by edt()
+
+    occupancy_grid() = default;
+    occupancy_grid(const bounding_rect& br, int cells_x, int cells_y)
+        : W(cells_x), H(cells_y), resolution((br.x_max - br.x_min) / (float)cells_x), bound_rect(br),
+          occ((size_t)cells_x * cells_y, 0) {}
+
+    int cell_x(float x) const { return std::clamp((int)std::floor((x - bound_rect.x_min) / resolution), 0, W - 1); }
+    int cell_y(float y) const { return std::clamp((int)std::floor((y - bound_rect.y_min) / ((bound_rect.y_max - bound_rect.y_min) / (float)H)), 0, H - 1); }
+    int32_t cell_of(const Vector2f& p) const { return cell_y(p.y()) * W + cell_x(p.x()); }
+    Vector2f centre_of(int32_t c) const {
+        const float ry = (bound_rect.y_max - bound_rect.y_min) / (float)H;
+        return Vector2f(bound_rect.x_min + ((c % W) + 0.5f) * resolution, bound_rect.y_min + ((c / W) + 0.5f) * ry);
+    }
+    // mark every cell whose centre lies inside a closed obstacle or that an obstacle edge passes through
+    void rasterize(const std::vector<obstacle>& obstacles) {
+        const float ry = (bound_rect.y_max - bound_rect.y_min) / (float)H;
+        for (const auto& ob : obstacles) {
+            if (ob.lines.empty()) continue;
+            if (ob.closed) {
+                const int x0 = cell_x(ob.bound_rect.x_min), x1 = cell_x(ob.bound_rect.x_max);
+                const int y0 = cell_y(ob.bound_rect.y_min), y1 = cell_y(ob.bound_rect.y_max);
+                for (int iy = y0; iy <= y1; ++iy)
+                    for (int ix = x0; ix <= x1; ++ix)
+                        if (ob.contains(centre_of(iy * W + ix))) occ[(size_t)iy * W + ix] = 1;
+            }
+            for (const auto& [a, b] : ob.lines) {  // edges: sample at sub-cell steps
+                const float len = (b - a).norm();
+                const int n = std::max(1, (int)std::ceil(len / (0.5f * std::min(resolution, ry))));
+                for (int k = 0; k <= n; ++k) occ[(size_t)cell_of(a + (b - a) * ((float)k / n))] = 1;
+            }
+        }
+    }
+    // exact squared EDT on the GPU
+    void edt(gpu_context& ctx = default_context()) {
+        d2.resize(occ.size());
+        ctx.check(sc_edt_u8_i32_host(ctx.get(), occ.data(), W, H, 1, d2.data()), "sc_edt_u8_i32_host");
+    }
+    struct batch_result {
+        std::vector<int32_t> path, len, cost, status;  // path is [Q][Lmax]
+        int Lmax = 0;
+    };
+    // Q independent start->goal queries (linear cell indices); r2_clear = squared clearance in cells
+    batch_result astar_batch(const std::vector<int32_t>& start, const std::vector<int32_t>& goal, int32_t r2_clear = 0,
+                             int Lmax = 0, gpu_context& ctx = default_context()) {
+        if (d2.size() != occ.size()) edt(ctx);
+        batch_result r;
+        const int Q = (int)start.size();
+        r.Lmax = Lmax > 0 ? Lmax : 4 * (W + H);
+        r.path.assign((size_t)Q * r.Lmax, -1); r.len.assign(Q, 0); r.cost.assign(Q, -1); r.status.assign(Q, SC_Q_NO_PATH);
+        if (Q == 0) return r;
+        ctx.check(sc_astar_batch_host(ctx.get(), d2.data(), W, H, r2_clear, start.data(), goal.data(), Q, r.Lmax,
+                                      r.path.data(), r.len.data(), r.cost.data(), r.status.data()), "sc_astar_batch_host");
+        return r;
+    }
+};
+
+// ---- planning_space (sea_current.hpp:298-319, 1272-1407) --------------------------------------------
+class planning_space {
+public:
+    std::vector<obstacle> obstacles;
+    std::vector<std::function<bool(Vector2f)>> free_space_allocations;
+    bounding_rect bound_rect;
+    int grid_cells = 256;       // cells along the longer side of bound_rect (new knob)
+    float clearance = 0.0f;     // required obstacle clearance in world units (new knob)
+
+    planning_space(const bounding_rect& br) : bound_rect(br) {}
+
+    std::tuple<bool, obstacle> is_obstacle(const Vector2f& p) {
+        for (auto& ob : obstacles)
+            if (ob.contains(p)) return {true, ob};
+        return {false, obstacle()};
+    }
+    bool is_free_space_allocated(const Vector2f& p) {
+        for (auto& f : free_space_allocations)
+            if (f(p)) return true;
+        return false;
+    }
+    bool is_free(const Vector2f& p) { return !std::get<0>(is_obstacle(p)) && is_free_space_allocated(p); }
+    // length of segment ab, FLT_MAX if it crosses any obstacle edge (:1315-1326)
+    float cost(const Vector2f a, const Vector2f b) const {
+        for (const auto& ob : obstacles)
+            for (const auto& [p, q] : ob.lines)
+                if (std::get<0>(intersects(a, b, p, q))) return FLT_MAX;
+        return pt_dist(a, b);
+    }
+    occupancy_grid make_grid() const {
+        const float wx = bound_rect.x_max - bound_rect.x_min, wy = bound_rect.y_max - bound_rect.y_min;
+        const float res = std::max(wx, wy) / (float)grid_cells;
+        occupancy_grid g(bound_rect, std::max(1, (int)std::ceil(wx / res)), std::max(1, (int)std::ceil(wy / res)));
+        g.rasterize(obstacles);
+        return g;
+    }
+    // Same role and result type as the reference's FMT* planner: start -> goal waypoint list, nullopt if
+    // no path.  `n` and `rn` (sample count, connection radius) are accepted for source compatibility;
+    // the grid resolution is `grid_cells`.
+    std::optional<std::vector<Vector2f>> fast_marching_trees(const Vector2f& x_init, const Vector2f& x_goal, const int n = 0, const float rn = 0) {
+        (void)n; (void)rn;
+        auto r = plan_batch({x_init}, {x_goal});
+        return r[0];
+    }
+    // batched form: one grid, one EDT, Q queries in one GPU launch
+    std::vector<std::optional<std::vector<Vector2f>>> plan_batch(const std::vector<Vector2f>& starts, const std::vector<Vector2f>& goals,
+                                                                 gpu_context& ctx = default_context()) {
+        occupancy_grid g = make_grid();
+        g.edt(ctx);
+        std::vector<int32_t> s(starts.size()), t(goals.size());
+        for (size_t i = 0; i < starts.size(); ++i) { s[i] = g.cell_of(starts[i]); t[i] = g.cell_of(goals[i]); }
+        const float cc = clearance / g.resolution;
+        auto br = g.astar_batch(s, t, (int32_t)std::ceil(cc * cc), 0, ctx);
+        std::vector<std::optional<std::vector<Vector2f>>> out(starts.size());
+        for (size_t q = 0; q < starts.size(); ++q) {
+            if (br.status[q] != SC_Q_OK) continue;
+            std::vector<Vector2f> wp;
+            wp.reserve(br.len[q] + 2);
+            wp.push_back(starts[q]);
+            for (int i = 1; i + 1 < br.len[q]; ++i) wp.push_back(g.centre_of(br.path[(size_t)q * br.Lmax + i]));
+            wp.push_back(goals[q]);
+            out[q] = std::move(wp);
+        }
+        return out;
+    }
+};
+
+// ---- velocity profile (sea_current.hpp:379-386, 1172-1265) ------------------------------------------
+struct velocity_profile {
+    std::vector<VectorXf> pos;
+    std::vector<VectorXf> vel;
+    std::vector<VectorXf> acc;
+    toppra_compat::Vector time;
+    velocity_profile(std::vector<VectorXf> pos, std::vector<VectorXf> vel, std::vector<VectorXf> acc, toppra_compat::Vector time)
+        : pos(std::move(pos)), vel(std::move(vel)), acc(std::move(acc)), time(std::move(time)) {}
+};
+
+// limits as a function of the GRIDPOINT value s in [0,1] (the reference names the argument "time", :1175, :1185)
+using vel_lim_func = std::function<std::tuple<toppra_compat::Vector, toppra_compat::Vector>(value_type time)>;
+
+constexpr int SC_TOPPRA_GRID = 100;  // toppra's default number of grid intervals (confirmed by examples/output.json)
+
+// P plans of `dof` joints in one GPU launch.  Arrays are [P][dof] row-major; limits per plan.
+struct plan_request {
+    std::vector<double> pos_end, pos_start, vel_end, vel_start, acc_min, acc_max;  // [dof] each
+    vel_lim_func vel_lim;
+};
+inline std::vector<velocity_profile> gen_vel_prof_batch(const std::vector<plan_request>& plans, const float dt = 0.02f,
+                                                        gpu_context& ctx = default_context()) {
+    const int P = (int)plans.size();
+    if (P == 0) return {};
+    const int dof = (int)plans[0].pos_end.size(), N = SC_TOPPRA_GRID;
+    std::vector<double> p0((size_t)P * dof), p1(p0), v0(p0), v1(p0), alo(p0), ahi(p0);
+    std::vector<double> vlo((size_t)P * (N + 1) * dof), vhi(vlo);
+    for (int p = 0; p < P; ++p) {
+        const auto& r = plans[p];
+        SC_ASSERT((int)r.pos_end.size() == dof, "all plans of a batch must have the same dof");
+        for (int k = 0; k < dof; ++k) {
+            const size_t o = (size_t)p * dof + k;
+            p0[o] = r.pos_start[k]; p1[o] = r.pos_end[k]; v0[o] = r.vel_start[k]; v1[o] = r.vel_end[k];
+            alo[o] = r.acc_min[k]; ahi[o] = r.acc_max[k];
+        }
+        for (int i = 0; i <= N; ++i) {
+            auto [lo, hi] = r.vel_lim((double)i / N);
+            for (int k = 0; k < dof; ++k) {
+                // the reference's LinearJointVelocityVarying is built with size-1 limit vectors (:1179);
+                // a 1-vector is broadcast over the joints
+                vlo[((size_t)p * (N + 1) + i) * dof + k] = lo((size_t)lo.rows() == 1 ? 0 : k);
+                vhi[((size_t)p * (N + 1) + i) * dof + k] = hi((size_t)hi.rows() == 1 ? 0 : k);
+            }
+        }
+    }
+    std::vector<double> K((size_t)P * (N + 1) * 2), x((size_t)P * (N + 1)), u((size_t)P * N), t((size_t)P * (N + 1));
+    std::vector<int32_t> status(P);
+    ctx.check(sc_toppra_hermite_batch_host(ctx.get(), P, dof, N, p0.data(), p1.data(), v0.data(), v1.data(), vlo.data(), vhi.data(), 1,
+                                           alo.data(), ahi.data(), 0.0, 0.0, K.data(), x.data(), u.data(), t.data(), status.data()),
+              "sc_toppra_hermite_batch_host");
+    int max_len = 1;
+    for (int p = 0; p < P; ++p) {
+        SC_ASSERT(status[p] == 0, "TOPP-RA failed");  // the reference only SC_ASSERTs the return code (:1227)
+        max_len = std::max(max_len, (int)std::ceil(t[(size_t)p * (N + 1) + N] / (double)dt) + 1);
+    }
+    std::vector<float> pos((size_t)P * dof * max_len), vel(pos.size()), acc(pos.size());
+    std::vector<double> times((size_t)P * max_len);
+    std::vector<int32_t> length(P);
+    ctx.check(sc_toppra_sample_batch_host(ctx.get(), P, dof, N, p0.data(), p1.data(), v0.data(), v1.data(), x.data(), t.data(), (double)dt,
+                                          max_len, pos.data(), vel.data(), acc.data(), times.data(), length.data()),
+              "sc_toppra_sample_batch_host");
+    std::vector<velocity_profile> out;
+    out.reserve(P);
+    for (int p = 0; p < P; ++p) {
+        const int L = std::min(length[p], max_len);
+        std::vector<VectorXf> ps(dof, VectorXf::Zero(L)), vs(dof, VectorXf::Zero(L)), as(dof, VectorXf::Zero(L));
+        toppra_compat::Vector tm(L);
+        for (int k = 0; k < dof; ++k)
+            for (int j = 0; j < L; ++j) {
+                const size_t o = ((size_t)p * dof + k) * max_len + j;
+                ps[k](j) = pos[o]; vs[k](j) = vel[o]; as[k](j) = acc[o];
+            }
+        for (int j = 0; j < L; ++j) tm(j) = times[(size_t)p * max_len + j];
+        out.emplace_back(std::move(ps), std::move(vs), std::move(as), std::move(tm));
+    }
+    return out;
+}
+
+// Same argument order as the reference: END before START (sea_current.hpp:1191-1199).
+template <int N>
+velocity_profile gen_vel_prof(const VectorNd<N>& pos_end, const VectorNd<N>& pos_start, const VectorNd<N>& vel_end,
+                              const VectorNd<N>& vel_start, const vel_lim_func& vel_lim, const VectorNd<N>& acc_min,
+                              const VectorNd<N>& acc_max, const float dt = 0.02f) {
+    static_assert(N >= 1, "gen_vel_prof needs at least one degree of freedom");
+    plan_request r;
+    for (int k = 0; k < N; ++k) {
+        r.pos_end.push_back(pos_end(k)); r.pos_start.push_back(pos_start(k));
+        r.vel_end.push_back(vel_end(k)); r.vel_start.push_back(vel_start(k));
+        r.acc_min.push_back(acc_min(k)); r.acc_max.push_back(acc_max(k));
+    }
+    r.vel_lim = vel_lim;
+    return std::move(gen_vel_prof_batch({r}, dt)[0]);
+}
+
+}  // namespace turtle::sc

@@ -1,0 +1,61 @@
+// Drives sea-current_amd/sea_current.hpp the way the reference's examples drive its header
+// (inputs: examples/test.cpp:249-284 obstacles and FMT* query; examples/zmq_test.py:7-10 +
+// examples/output.json for the 1-DOF velocity profile).  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+
+#include "../../sea-current_amd/sea_current.hpp"
+
+using namespace turtle::sc;
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } \
+    } while (0)
+
+int main() {
+    // --- planning path: examples/test.cpp:249-284 ---
+    const bounding_rect br = {1, -1, 1, -1};
+    planning_space space(br);
+    obstacle ob({Vector2f(-0.5, 0), Vector2f(1, 0), Vector2f(1, 1), Vector2f(0, 1)});
+    obstacle ob2({Vector2f(0, -0.5), Vector2f(1, 0), Vector2f(1, 1), Vector2f(0, 1)});
+    obstacle ob3({Vector2f(-0.6, 0.148), Vector2f(-1, 0.148), Vector2f(-1, 0), Vector2f(-0.6, 0)});
+    space.obstacles = {ob, ob2, ob3};
+    CHECK(ob.contains(Vector2f(0.5, 0.5)));              // examples/test.cpp:272 prints 1
+    CHECK(!ob.contains(Vector2f(-0.9, -0.9)));
+    CHECK(std::get<0>(space.is_obstacle(Vector2f(0.5, 0.5))));
+    CHECK(space.cost(Vector2f(-0.9, -0.9), Vector2f(-0.8, -0.9)) < 1.0f);
+    CHECK(space.cost(Vector2f(-0.9, 0.5), Vector2f(0.9, 0.5)) == FLT_MAX);
+    auto path = space.fast_marching_trees(Vector2f(-0.5, 1), Vector2f(1, -1), 200, 1);  // same call as :284
+    CHECK(path.has_value());
+    CHECK(path->size() > 2);
+    CHECK(path->front() == Vector2f(-0.5, 1) && path->back() == Vector2f(1, -1));
+    for (size_t i = 1; i + 2 < path->size(); ++i) {  // interior legs join free cell centres
+        CHECK(!std::get<0>(space.is_obstacle((*path)[i])));
+        CHECK(space.cost((*path)[i], (*path)[i + 1]) < FLT_MAX);
+    }
+    // a goal inside an obstacle has no path (nullopt, as :1383-1385)
+    CHECK(!space.fast_marching_trees(Vector2f(-0.5, 1), Vector2f(0.5, 0.5)).has_value());
+    // batched form agrees with the single call
+    auto batch = space.plan_batch({Vector2f(-0.5, 1), Vector2f(-0.9, -0.9)}, {Vector2f(1, -1), Vector2f(0.9, -0.9)});
+    CHECK(batch.size() == 2 && batch[0].has_value() && batch[1].has_value());
+    CHECK(batch[0]->size() == path->size());
+
+    // --- velocity profile: examples/zmq_test.cpp:69-88 with the recorded arclength of output.json ---
+    const double L = 21.38861656188965;
+    auto vel_lim = [&](value_type) {
+        toppra_compat::Vector lo(1), hi(1);
+        lo(0) = -0.25; hi(0) = 0.25;
+        return std::make_tuple(lo, hi);
+    };
+    velocity_profile prof = gen_vel_prof<1>(VectorNd<1>{L}, VectorNd<1>{0}, VectorNd<1>{0}, VectorNd<1>{0}, vel_lim,
+                                            VectorNd<1>{-0.5}, VectorNd<1>{0.5});
+    CHECK(prof.pos.size() == 1 && prof.pos[0].rows() == 4328);      // output.json: 4328 samples
+    CHECK(std::fabs(prof.time(4327) - 86.55526) < 1e-4);            // output.json: T = 86.55526
+    float vmax = 0, amax = 0;
+    for (int i = 0; i < 4328; ++i) { vmax = std::max(vmax, prof.vel[0](i)); amax = std::max(amax, std::fabs(prof.acc[0](i))); }
+    CHECK(std::fabs(vmax - 0.253140f) < 2e-6f);                     // BASELINE.md extrema
+    CHECK(std::fabs(amax - 0.497336f) < 2e-6f);
+    std::printf("sea_current.hpp: planning path + velocity profile OK (%zu waypoints, %d samples)\n", path->size(), 4328);
+    return 0;
+}
