@@ -32,6 +32,7 @@
 // expansion order.
 #include "sc_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define NBUCKET 32
 #define Q_OVERFLOW 100  // internal: bucket ring overflow, retried by the host with a larger ring
@@ -69,6 +70,17 @@ __device__ __forceinline__ int octile(int x, int y, int gx, int gy) {
 __device__ __forceinline__ uint32_t g_load(const uint32_t* p) {
     // agent-scope relaxed load: served by L2, where this wave's atomicMin results live
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Relaxations that can never improve anything are pruned at insertion time.  If c was reached from
+// its parent p by move d, a neighbour n of c that p can also reach by ONE legal move e was already
+// relaxed by p at a cost <= the cost through c (and n == p trivially).  ALWAYS[d]: the three
+// neighbours for which p's move is legal whenever c's is (reverse direction and the two cells that
+// touch p).  For straight d two more (the cells diagonal to p) depend on p's own move mask.
+__device__ __forceinline__ uint32_t prune_always(int d) {
+    // d: 0 E, 1 W, 2 S(+y), 3 N, 4 SE, 5 SW, 6 NE, 7 NW
+    const unsigned long long T = 0x1526498A34C851A2ull;  // bytes: A2 51 C8 34 8A 49 26 15
+    return (uint32_t)(T >> (8 * d)) & 0xFFu;
 }
 
 __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
@@ -111,9 +123,21 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     uint32_t* bk = a.buckets + (size_t)slot * NBUCKET * a.cap;
     const int cap = a.cap, capm = a.cap - 1;
     const int sx = s % W, sy = s / W, gx = t % W, gy = t / W;
-    const int off[8] = {1, -1, W, -W, W + 1, W - 1, -W + 1, -W - 1};
     const int ddx[8] = {1, -1, 0, 0, 1, -1, 1, -1};
     const int ddy[8] = {0, 0, 1, -1, 1, 1, -1, -1};
+
+    // Lane layout: 8 lanes per node, one per move.  `d` is this lane's move for the whole kernel.
+    const int d = lane & 7, sub = lane >> 3;
+    const int mdx = (int)((0x2252u >> (2 * d)) & 3u) - 1;   // {1,-1,0,0,1,-1,1,-1}
+    const int mdy = (int)((0x0A25u >> (2 * d)) & 3u) - 1;   // {0,0,1,-1,1,1,-1,-1}
+    const uint32_t mw = d < 4 ? 10u : 14u;
+    const int moff = mdy * W + mdx;
+    // pruning of the successor this lane creates (it arrives by move d)
+    const uint32_t p_always = prune_always(d);
+    // straight d: neighbour k of the successor is also reachable from the parent by diagonal e
+    const int ck0 = d < 2 ? 3 : 0, ce0 = (int)((0x6476u >> (4 * (d & 3))) & 7u);   // E:(N,NE) W:(N,NW) S:(E,SE) N:(E,NE)
+    const int ck1 = d < 2 ? 2 : 1, ce1 = (int)((0x7554u >> (4 * (d & 3))) & 7u);   // E:(S,SE) W:(S,SW) S:(W,SW) N:(W,NW)
+    const bool p_cond = d < 4;
 
     int fcur = octile(sx, sy, gx, gy);
     if (lane == 0) {
@@ -126,6 +150,10 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
 
     bool found = false, overflow = false;
     int nexp = 0, niter = 0;
+#ifdef ASTAR_STAMPS
+    unsigned long long st_pop = 0, st_mem = 0, st_rest = 0;
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
     dbg_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -134,96 +162,216 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         uint32_t* bq = bk + (size_t)b * cap;
         // drain everything with f == fcur: the LDS ring first, then what earlier levels left in HBM
         for (;;) {
-            int cx = 0, cy = 0, c = 0;
-            uint32_t gc = 0, mv = 0;
-            bool valid = false;
-            if (lt != lh) {
-                const int n = min(64, lt - lh);
-                if (lane < n) {
-                    const uint32_t xy = qxy[(lh + lane) & (CQ - 1)];
-                    mv = qmv[(lh + lane) & (CQ - 1)];
-                    cx = xy & 0xFFFF; cy = xy >> 16;
-                    c = cy * W + cx;
-                    gc = (uint32_t)(fcur - octile(cx, cy, gx, gy));  // never stale: g = f - h
-                    valid = true;
-                }
-                lh += n;
-            } else {
-                const int hd = HEAD(b), tl = TAIL(b);
+            int n;
+            bool from_lds;
+            int hd = 0;
+            if (lt != lh) { n = min(64, lt - lh); from_lds = true; }
+            else {
+                hd = HEAD(b);
+                const int tl = TAIL(b);
                 if (hd == tl) break;
-                const int n = min(64, tl - hd);
-                if (lane < n) {
-                    const uint32_t xy = bq[(hd + lane) & capm];
-                    cx = xy & 0xFFFF; cy = xy >> 16;
-                    c = cy * W + cx;
-                    const uint32_t gv = g_load(&g[c]);
-                    mv = a.moves[c];
-                    gc = gv & gmask;
-                    // stale unless it still carries this launch's tag and the g that put it in this bucket
-                    valid = (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
-                }
-                vhead = lane == b ? hd + n : vhead;
+                n = min(64, tl - hd);
+                from_lds = false;
             }
-            if (!valid) mv = 0;
+            const int K = (n + 7) >> 3;  // groups of 8 nodes (x 8 moves = 64 lanes)
             ++niter;
-            nexp += __popcll(__ballot(valid));
-            if (__ballot(valid && c == t)) found = true;
-            // Scattered returning atomics are the scarcest resource of this kernel (one request per
-            // lane, ~20 G/s chip-wide), so neighbours are first filtered with plain L2 loads of g: only
-            // candidates that can still improve (about one in six) go on to the atomicMin, and only
-            // those fetch their move mask.
-            uint32_t old[8], nmv[8];
+            // The step is instantiated for 1, 2, 4 or 8 groups: narrow frontiers (the common case on
+            // dense maps) then run ~1/8 of the instructions of a full 64-node step.
+            auto step = [&](auto km_tag) {
+                constexpr int KM = decltype(km_tag)::value;
+#ifdef ASTAR_STAMPS
+                const unsigned long long ts0 = STAMP();
+#endif
+                int cx[KM], cy[KM];
+                uint32_t gc[KM], mv[KM];
+                bool valid[KM];
+                if (from_lds) {
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                old[d] = 0;
-                if ((mv >> d) & 1) old[d] = g_load(&g[c + off[d]]);
-            }
-            uint32_t cand = 0;
-#pragma unroll
-            for (int d = 0; d < 8; ++d)
-                if (((mv >> d) & 1) && old[d] > (etag | (gc + (d < 4 ? 10u : 14u)))) cand |= 1u << d;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                nmv[d] = 0;
-                if ((cand >> d) & 1) {
-                    old[d] = __hip_atomic_fetch_min(&g[c + off[d]], etag | (gc + (d < 4 ? 10u : 14u)), __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    nmv[d] = a.moves[c + off[d]];
-                }
-            }
-            mv = cand;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const uint32_t ng = gc + (d < 4 ? 10u : 14u);
-                const bool imp = ((mv >> d) & 1) && old[d] > (etag | ng);
-                const int nx = cx + ddx[d], ny = cy + ddy[d];
-                const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;  // in {0,6,8,14,20,28}
-                unsigned long long rem = __ballot(imp);
-                while (rem) {
-                    const int leader = __ffsll((long long)rem) - 1;
-                    const int v = __builtin_amdgcn_readlane(df, leader);
-                    const bool mine = imp && df == v;
-                    const unsigned long long m = __ballot(mine);
-                    const int cnt = __popcll(m);
-                    const int rank = __popcll(m & lt_mask);
-                    if (v == 0 && lt - lh + cnt <= CQ) {
-                        if (mine) {
-                            qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
-                            qmv[(lt + rank) & (CQ - 1)] = (uint8_t)nmv[d];
-                        }
-                        lt += cnt;
-                    } else {
-                        const int bb = (fcur + v) & 31;
-                        const int base = TAIL(bb);
-                        if (base + cnt - HEAD(bb) > cap) overflow = true;
-                        else {
-                            if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | nx);
-                            vtail = lane == bb ? base + cnt : vtail;
+                    for (int k = 0; k < KM; ++k) {
+                        valid[k] = false; cx[k] = cy[k] = 0; gc[k] = 0; mv[k] = 0;
+                        if (8 * k + sub < n) {
+                            const uint32_t xy = qxy[(lh + 8 * k + sub) & (CQ - 1)];
+                            mv[k] = qmv[(lh + 8 * k + sub) & (CQ - 1)];
+                            cx[k] = xy & 0xFFFF; cy[k] = xy >> 16;
+                            gc[k] = (uint32_t)(fcur - octile(cx[k], cy[k], gx, gy));  // never stale: g = f - h
+                            valid[k] = true;
                         }
                     }
-                    rem &= ~m;
+                    lh += n;
+                } else {
+                    uint32_t gv[KM], mm[KM], de[KM];
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        valid[k] = false; cx[k] = cy[k] = 0; gv[k] = 0; mm[k] = 0; de[k] = 0;
+                        if (8 * k + sub < n) {
+                            const uint32_t e = bq[(hd + 8 * k + sub) & capm];
+                            cx[k] = e & 0x1FFF; de[k] = (e >> 13) & 7; cy[k] = e >> 16;
+                            const int c = cy[k] * W + cx[k];
+                            gv[k] = g_load(&g[c]);
+                            mm[k] = a.moves[c];
+                            valid[k] = true;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        gc[k] = gv[k] & gmask;
+                        // stale unless it still carries this launch's tag and the g that put it in this bucket
+                        valid[k] = valid[k] && (gv[k] & ~gmask) == etag && (int)(gc[k] + octile(cx[k], cy[k], gx, gy)) == fcur;
+                        mv[k] = mm[k] & ~prune_always((int)de[k]);
+                    }
+                    vhead = lane == b ? hd + n : vhead;
                 }
-            }
+#ifdef ASTAR_STAMPS
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long ts1 = STAMP();
+#endif
+                // ---- relax: every lane handles move d of its node; all groups' memory operations first ----
+                uint32_t old[KM], nmv[KM];
+                bool legal[KM];
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    // Issued unconditionally: a divergent `if` around each atomic makes the compiler drain
+                    // vmcnt before every one of them (8 dependent round trips per step).  Lanes without a
+                    // legal move send the no-op operand 0xFFFFFFFF to a harmless cell of the slot.
+                    legal[k] = valid[k] && ((mv[k] >> d) & 1);
+                    const int nidx = legal[k] ? cy[k] * W + cx[k] + moff : lane;
+                    old[k] = __hip_atomic_fetch_min(&g[nidx], legal[k] ? (etag | (gc[k] + mw)) : 0xFFFFFFFFu, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    nmv[k] = a.moves[nidx];
+                }
+#ifdef ASTAR_STAMPS
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long ts2 = STAMP();
+#endif
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    if (KM > 1 && k >= K) break;
+                    nexp += __popcll(__ballot(valid[k] && d == 0));
+                    if (__ballot(valid[k] && cy[k] * W + cx[k] == t)) found = true;
+                    const uint32_t ng = gc[k] + mw;
+                    const bool imp = legal[k] && old[k] > (etag | ng);
+                    const int nx = cx[k] + mdx, ny = cy[k] + mdy;
+                    const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;  // in {0,6,8,14,20,28}
+                    // moves worth trying from the successor
+                    uint32_t prune = p_always;
+                    if (p_cond) prune |= (((mv[k] >> ce0) & 1u) << ck0) | (((mv[k] >> ce1) & 1u) << ck1);
+                    const uint32_t smv = nmv[k] & ~prune;
+                    unsigned long long rem = __ballot(imp);
+                    while (rem) {
+                        const int leader = __ffsll((long long)rem) - 1;
+                        const int v = __builtin_amdgcn_readlane(df, leader);
+                        const bool mine = imp && df == v;
+                        const unsigned long long m = __ballot(mine);
+                        const int cnt = __popcll(m);
+                        const int rank = __popcll(m & lt_mask);
+                        if (v == 0 && lt - lh + cnt <= CQ) {
+                            if (mine) {
+                                qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
+                                qmv[(lt + rank) & (CQ - 1)] = (uint8_t)smv;
+                            }
+                            lt += cnt;
+                        } else {
+                            const int bb = (fcur + v) & 31;
+                            const int base = TAIL(bb);
+                            if (base + cnt - HEAD(bb) > cap) overflow = true;
+                            else {
+                                if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | d << 13 | nx);
+                                vtail = lane == bb ? base + cnt : vtail;
+                            }
+                        }
+                        rem &= ~m;
+                    }
+                }
+#ifdef ASTAR_STAMPS
+                const unsigned long long ts3 = STAMP();
+                st_pop += ts1 - ts0; st_mem += ts2 - ts1; st_rest += ts3 - ts2;
+#endif
+            };
+            // Wide frontiers (more than 16 nodes): one lane per node, the 8 moves unrolled.  The cost of
+            // this form does not depend on the node count, so it wins as soon as 3+ groups are needed.
+            auto step_wide = [&]() {
+                int cx = 0, cy = 0;
+                uint32_t gc = 0, mv = 0;
+                bool valid = false;
+                if (from_lds) {
+                    if (lane < n) {
+                        const uint32_t xy = qxy[(lh + lane) & (CQ - 1)];
+                        mv = qmv[(lh + lane) & (CQ - 1)];
+                        cx = xy & 0xFFFF; cy = xy >> 16;
+                        gc = (uint32_t)(fcur - octile(cx, cy, gx, gy));
+                        valid = true;
+                    }
+                    lh += n;
+                } else {
+                    uint32_t gv = 0, mm = 0, de = 0;
+                    if (lane < n) {
+                        const uint32_t e = bq[(hd + lane) & capm];
+                        cx = e & 0x1FFF; de = (e >> 13) & 7; cy = e >> 16;
+                        gv = g_load(&g[cy * W + cx]);
+                        mm = a.moves[cy * W + cx];
+                        valid = true;
+                    }
+                    gc = gv & gmask;
+                    valid = valid && (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
+                    mv = mm & ~prune_always((int)de);
+                    vhead = lane == b ? hd + n : vhead;
+                }
+                if (!valid) mv = 0;
+                const int c = cy * W + cx;
+                nexp += __popcll(__ballot(valid));
+                if (__ballot(valid && c == t)) found = true;
+                const int off8[8] = {1, -1, W, -W, W + 1, W - 1, -W + 1, -W - 1};
+                uint32_t old[8], nmv[8];
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {   // unconditional issue (see the note in step())
+                    const bool lg = (mv >> dd) & 1;
+                    const int nidx = lg ? c + off8[dd] : lane;
+                    old[dd] = __hip_atomic_fetch_min(&g[nidx], lg ? (etag | (gc + (dd < 4 ? 10u : 14u))) : 0xFFFFFFFFu, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    nmv[dd] = a.moves[nidx];
+                }
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+                    const uint32_t ng = gc + (dd < 4 ? 10u : 14u);
+                    const bool imp = ((mv >> dd) & 1) && old[dd] > (etag | ng);
+                    const int nx = cx + ddx[dd], ny = cy + ddy[dd];
+                    const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;
+                    uint32_t prune = prune_always(dd);
+                    if (dd < 4) {
+                        const int k0 = dd < 2 ? 3 : 0, e0 = (0x6476 >> (4 * dd)) & 7, k1 = dd < 2 ? 2 : 1, e1 = (0x7554 >> (4 * dd)) & 7;
+                        prune |= (((mv >> e0) & 1u) << k0) | (((mv >> e1) & 1u) << k1);
+                    }
+                    const uint32_t smv = nmv[dd] & ~prune;
+                    unsigned long long rem = __ballot(imp);
+                    while (rem) {
+                        const int leader = __ffsll((long long)rem) - 1;
+                        const int v = __builtin_amdgcn_readlane(df, leader);
+                        const bool mine = imp && df == v;
+                        const unsigned long long m = __ballot(mine);
+                        const int cnt = __popcll(m);
+                        const int rank = __popcll(m & lt_mask);
+                        if (v == 0 && lt - lh + cnt <= CQ) {
+                            if (mine) {
+                                qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
+                                qmv[(lt + rank) & (CQ - 1)] = (uint8_t)smv;
+                            }
+                            lt += cnt;
+                        } else {
+                            const int bb = (fcur + v) & 31;
+                            const int base = TAIL(bb);
+                            if (base + cnt - HEAD(bb) > cap) overflow = true;
+                            else {
+                                if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | dd << 13 | nx);
+                                vtail = lane == bb ? base + cnt : vtail;
+                            }
+                        }
+                        rem &= ~m;
+                    }
+                }
+            };
+            if (K == 1) step(std::integral_constant<int, 1>{});
+            else if (K == 2) step(std::integral_constant<int, 2>{});
+            else step_wide();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (overflow) break;
         }
@@ -235,8 +383,12 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
         fcur += 1 + (__ffs((int)rot) - 1);
     }
-
     dbg_iter = niter;
+#ifdef ASTAR_STAMPS
+    if (lane == 0 && a.dbg) { a.dbg[2 * q] = (int)(st_pop >> 10); a.dbg[2 * q + 1] = (int)(st_mem >> 10); a.expanded[q] = (int)(st_rest >> 10); a.status[q] = niter; }
+    return;
+#endif
+
     if (overflow) { finish(Q_OVERFLOW, 0, -1, nexp); return; }
     if (!found) { finish(SC_Q_NO_PATH, 0, -1, nexp); return; }
 

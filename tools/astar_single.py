@@ -1,0 +1,18 @@
+"""Scratch: one A* query alone on the GPU (for PMC counting)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sea-current_amd", "python")); sys.path.insert(0, ROOT)
+os.environ["SC_ASTAR_DEBUG"] = "1"
+import numpy as np, torch
+import sea_current_amd as sc
+from sea_current_amd import synth
+ctx = sc.Context(0)
+occ = synth.salt_grid(1024, 1024, 0.2)
+d2 = ctx.edt(torch.from_numpy(occ).cuda()); torch.cuda.synchronize()
+s, g = synth.queries(d2.cpu().numpy() >= 1, 1024)
+j = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+s1 = torch.from_numpy(s[j:j + 1].copy()).cuda(); g1 = torch.from_numpy(g[j:j + 1].copy()).cuda()
+for _ in range(3): ctx.astar_batch(d2, s1, g1)
+torch.cuda.synchronize()
+ex, it = ctx.astar_debug_stats(1)
+print("query", j, "expansions", ex[0], "iters", it[0, 0], "kcycles", it[0, 1])
