@@ -60,10 +60,12 @@ def main():
     ap.add_argument("--map", default="salt20", choices=list(FAMILIES),
                     help="obstacle family of the headline numbers (the other two are reported under other_maps)")
     ap.add_argument("--only-main-map", action="store_true")
+    ap.add_argument("--depth", type=int, default=4,
+                    help="independent steps in flight (own context/stream each); 1 = strictly sequential steps")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,37 +96,76 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_map(family, steps, warmup):
-        """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ all-gather])."""
+    import threading
+    depth_max = max(1, args.depth)
+    slot_ctx = [ctx] + [sc.Context(local_rank, use_torch_stream=False) for _ in range(depth_max - 1)]
+    if depth_max > 1:
+        ctx.use_own_stream()
+
+    def run_map(family, steps, warmup, depth):
+        """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ all-gather]).
+
+        depth == 1: strictly sequential steps.  depth > 1: consecutive steps are independent batches, so
+        they are executed by `depth` slots (own sc_ctx + HIP stream + output buffers + host thread) and
+        overlap on the GPU -- an A* batch ends with its slowest query, which leaves most CUs idle for
+        most of a step.  Every step still runs its own EDT and A* over all its queries; the gather of
+        step i is issued by the main thread, in step order, once slot i % depth has finished it."""
         occ_h = make_grid(family, W, H)
         occ = torch.from_numpy(occ_h).to(dev)
-        d2 = torch.empty((H, W), dtype=torch.int32, device=dev)
-        ctx.edt(occ, out=d2.view(1, H, W))
+        d2s = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(depth)]
+        ctx.edt(occ, out=d2s[0].view(1, H, W))
+        ctx.synchronize()
         torch.cuda.synchronize()
         # queries are drawn from the largest free component (needs the traversable mask once, on the host)
-        s_h, g_h = synth.queries(d2.cpu().numpy() >= 1, q1 - q0, first=q0)
+        s_h, g_h = synth.queries(d2s[0].cpu().numpy() >= 1, q1 - q0, first=q0)
         start = torch.from_numpy(s_h).to(dev)
         goal = torch.from_numpy(g_h).to(dev)
-        out = dict(path=torch.empty((Qloc, args.lmax), dtype=torch.int32, device=dev),
-                   len=torch.empty(Qloc, dtype=torch.int32, device=dev),
-                   cost=torch.empty(Qloc, dtype=torch.int32, device=dev),
-                   status=torch.empty(Qloc, dtype=torch.int32, device=dev))
-        gathered = shard.alloc_gather(out, world) if world > 1 else None
+        outs = [dict(path=torch.empty((Qloc, args.lmax), dtype=torch.int32, device=dev),
+                     len=torch.empty(Qloc, dtype=torch.int32, device=dev),
+                     cost=torch.empty(Qloc, dtype=torch.int32, device=dev),
+                     status=torch.empty(Qloc, dtype=torch.int32, device=dev)) for _ in range(depth)]
+        gathered = [shard.alloc_gather(outs[j], world) if world > 1 else None for j in range(depth)]
+        torch.cuda.synchronize()
 
-        def step():
-            ctx.edt(occ, out=d2.view(1, H, W))
-            ctx.astar_batch(d2, start, goal, r2=0, Lmax=args.lmax, out=out)
-            if world > 1:
-                shard.allgather_paths(out, gathered, dist)
+        def run_steps(nsteps):
+            done = [threading.Event() for _ in range(nsteps)]
+            released = [threading.Event() for _ in range(nsteps)]
+            errors = []
 
-        for _ in range(warmup):
-            step()
+            def worker(j):
+                try:
+                    for i in range(j, nsteps, depth):
+                        if i - depth >= 0:
+                            released[i - depth].wait()      # this slot's buffers have been gathered
+                        slot_ctx[j].edt(occ, out=d2s[j].view(1, H, W))
+                        slot_ctx[j].astar_batch(d2s[j], start, goal, r2=0, Lmax=args.lmax, out=outs[j])
+                        slot_ctx[j].synchronize()
+                        done[i].set()
+                except Exception as e:  # surface failures of worker threads
+                    errors.append(e)
+                    for ev in done:
+                        ev.set()
+
+            ths = [threading.Thread(target=worker, args=(j,)) for j in range(depth)]
+            for t in ths:
+                t.start()
+            for i in range(nsteps):
+                done[i].wait()
+                if world > 1 and not errors:
+                    shard.allgather_paths(outs[i % depth], gathered[i % depth], dist)
+                    torch.cuda.current_stream().synchronize()
+                released[i].set()
+            for t in ths:
+                t.join()
+            if errors:
+                raise errors[0]
+
+        run_steps(max(warmup, depth))   # every slot allocates its scratch on its first step: keep that out of the timed region
         fence()
         ctx.set_timing(True)
         ctx.reset_timing()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run_steps(steps)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -132,11 +173,13 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         step_kernels = {}
+        nslot0 = max(1, len(range(0, steps, depth)))   # timing is collected on slot 0 only
         for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR)):
             ms, n = ctx.get_timing(kid)
-            step_kernels[name] = {"ms_per_step": ms / max(steps, 1), "launches": n}
+            step_kernels[name] = {"ms_per_step": ms / nslot0, "launches": n}
         ctx.set_timing(False)
         expansions = ctx.astar_last_expansions()
+        out = outs[0]
         st = out["status"].cpu().numpy()
         ln = out["len"].cpu().numpy()
         astar_ms = step_kernels["astar"]["ms_per_step"]
@@ -148,8 +191,9 @@ def main():
                            "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
                     _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st))
 
-    main_run = run_map(args.map, args.steps, args.warmup)
-    others = {} if args.only_main_map else {f: run_map(f, max(2, min(args.steps, 3)), 1) for f in FAMILIES if f != args.map}
+    main_run = run_map(args.map, args.steps, args.warmup, depth_max)
+    seq_run = run_map(args.map, max(2, min(args.steps, 3)), 1, 1) if depth_max > 1 else main_run
+    others = {} if args.only_main_map else {f: run_map(f, max(depth_max, min(args.steps, 4)), 1, depth_max) for f in FAMILIES if f != args.map}
     occ_h, s_h, g_h, out, st = (main_run["_host"][k] for k in ("occ", "s", "g", "out", "st"))
 
     result = None
@@ -161,7 +205,8 @@ def main():
             "config": {"workload": f"{W}x{H} random-obstacle grid ({args.map}), EDT + A*, {Qloc} batched queries per GPU"
                                    + (", RCCL all-gather of paths" if world > 1 else ""),
                        "grid": [W, H], "map": args.map, "queries_per_gpu": Qloc, "queries_total": Qtot, "lmax": args.lmax,
-                       "parallelism": f"query-sharded x{world}"},
+                       "parallelism": f"query-sharded x{world}", "pipeline_depth": depth_max},
+            "latency_ms_per_step_sequential": seq_run["ms_per_step"], "value_sequential": seq_run["value"],
             "step_kernels": main_run["step_kernels"], "astar": main_run["astar"],
             "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"], "astar_ms_per_step": r["step_kernels"]["astar"]["ms_per_step"],
                                "expansions_per_step_rank0": r["astar"]["expansions_per_step_rank0"]} for f, r in others.items()},
@@ -244,28 +289,35 @@ def main():
         t0 = time.perf_counter()
         d2_ref = oracle.edt(occ_h)
         t_edt = time.perf_counter() - t0
-        # size the sample for ~cpu-seconds of work from a small probe
-        probe = min(2 * cores, Qloc)
-        t0 = time.perf_counter()
-        oracle.astar_batch(d2_ref, s_h[:probe], g_h[:probe], Lmax=args.lmax, nthreads=cores)
-        t_probe = max(time.perf_counter() - t0, 1e-6)
-        nq = int(min(Qloc, max(probe, args.cpu_seconds / t_probe * probe)))
-        t0 = time.perf_counter()
-        ref = oracle.astar_batch(d2_ref, s_h[:nq], g_h[:nq], Lmax=args.lmax, nthreads=cores)
-        t_as = time.perf_counter() - t0
-        # parity spot-check of what was just timed on the GPU (same queries)
-        pth = out["path"][:nq].cpu().numpy()
-        ok = bool(np.array_equal(ref["status"], st[:nq]) and np.array_equal(ref["cost"], out["cost"][:nq].cpu().numpy())
-                  and all(np.array_equal(pth[q, :ref["len"][q]], ref["path"][q, :ref["len"][q]]) for q in range(nq)))
-        result["cpu_baseline"] = {"value": nq / (t_edt + t_as), "unit": "plans/s", "cores": cores, "kind": "port",
-                                  "sample": f"exact EDT of the grid once ({t_edt:.3f} s, 1 thread) + first {nq} of the "
-                                            f"{Qloc} queries, A* on {cores} threads ({t_as:.2f} s); build's own C "
-                                            "restatement -- the reference has no grid path",
-                                  "edt_seconds_1thread": t_edt, "astar_expansions": int(ref["expanded"].sum()),
+        # bounded sample: whole query sets of the same workload (set k = queries k*Q .. (k+1)*Q-1 of the same
+        # generator; set 0 is exactly what the GPU just planned) until ~cpu-seconds of A* work have run
+        trav = d2_ref >= 1
+        t_as, nq, nexp, ref0 = 0.0, 0, 0, None
+        k = 0
+        while t_as < args.cpu_seconds and k < 64:
+            sk, gk = (s_h, g_h) if k == 0 else synth.queries(trav, Qloc, first=k * Qloc)
+            t0 = time.perf_counter()
+            ref = oracle.astar_batch(d2_ref, sk, gk, Lmax=args.lmax, nthreads=cores)
+            t_as += time.perf_counter() - t0
+            nq += Qloc
+            nexp += int(ref["expanded"].sum())
+            if k == 0:
+                ref0 = ref
+            k += 1
+        # parity spot-check of what was just timed on the GPU (set 0 = the same queries)
+        pth = out["path"].cpu().numpy()
+        ok = bool(np.array_equal(ref0["status"], st) and np.array_equal(ref0["cost"], out["cost"].cpu().numpy())
+                  and all(np.array_equal(pth[q, :ref0["len"][q]], ref0["path"][q, :ref0["len"][q]]) for q in range(Qloc)))
+        result["cpu_baseline"] = {"value": nq / (k * t_edt + t_as), "unit": "plans/s", "cores": cores, "kind": "port",
+                                  "sample": f"{k} query sets of {Qloc} (exact EDT of the grid per set: {t_edt:.3f} s, 1 thread; "
+                                            f"A* on {cores} threads: {t_as:.1f} s in total); build's own C restatement -- "
+                                            "the reference has no grid path",
+                                  "edt_seconds_1thread": t_edt, "astar_expansions": nexp,
                                   "gpu_matches_cpu_on_sample": ok}
     if rank == 0:
         print(json.dumps(result))
-    ctx.close()
+    for c in slot_ctx:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -72,6 +72,43 @@ __device__ __forceinline__ uint32_t g_load(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// N returning atomic-min operations issued back to back, each only on the lanes whose operand is not
+// 0xFFFFFFFF (a no-op for min).  hipcc drains vmcnt in front of every divergent `if (...) atomic`,
+// which turns N relaxations into N dependent round trips; issuing them unconditionally instead
+// doubles the scarce scattered-atomic request rate.  One asm statement with explicit EXEC masks
+// gives both: one round trip, no wasted requests.  The statement waits for its own results
+// (s_waitcnt vmcnt(0)), as required for asm-issued memory operations.
+#define ASTAR_MASKED_ATOMIC(k)                                              \
+    "s_mov_b64 exec, %[sv]\n\t"                                             \
+    "v_cmp_ne_u32_e32 vcc, -1, %[d" #k "]\n\t"                              \
+    "s_and_b64 exec, %[sv], vcc\n\t"                                        \
+    "global_atomic_umin %[o" #k "], %[a" #k "], %[d" #k "], off sc0\n\t"
+__device__ __forceinline__ void masked_atomic_min8(uint32_t* const (&ad)[8], const uint32_t (&dv)[8], uint32_t (&o)[8]) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 ASTAR_MASKED_ATOMIC(0) ASTAR_MASKED_ATOMIC(1) ASTAR_MASKED_ATOMIC(2) ASTAR_MASKED_ATOMIC(3)
+                 ASTAR_MASKED_ATOMIC(4) ASTAR_MASKED_ATOMIC(5) ASTAR_MASKED_ATOMIC(6) ASTAR_MASKED_ATOMIC(7)
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : [sv] "=&s"(sv), [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [o4] "+v"(o[4]),
+                   [o5] "+v"(o[5]), [o6] "+v"(o[6]), [o7] "+v"(o[7])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [a2] "v"(ad[2]), [a3] "v"(ad[3]), [a4] "v"(ad[4]), [a5] "v"(ad[5]),
+                   [a6] "v"(ad[6]), [a7] "v"(ad[7]), [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]),
+                   [d4] "v"(dv[4]), [d5] "v"(dv[5]), [d6] "v"(dv[6]), [d7] "v"(dv[7])
+                 : "vcc", "memory");
+}
+__device__ __forceinline__ void masked_atomic_min2(uint32_t* const (&ad)[2], const uint32_t (&dv)[2], uint32_t (&o)[2]) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 ASTAR_MASKED_ATOMIC(0) ASTAR_MASKED_ATOMIC(1)
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : [sv] "=&s"(sv), [o0] "+v"(o[0]), [o1] "+v"(o[1])
+                 : [a0] "v"(ad[0]), [a1] "v"(ad[1]), [d0] "v"(dv[0]), [d1] "v"(dv[1])
+                 : "vcc", "memory");
+}
+
 // Relaxations that can never improve anything are pruned at insertion time.  If c was reached from
 // its parent p by move d, a neighbour n of c that p can also reach by ONE legal move e was already
 // relaxed by p at a cost <= the cost through c (and n == p trivially).  ALWAYS[d]: the three
@@ -87,11 +124,12 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     // LDS ring of the current f level (indexed directly so that the accesses stay ds_* instructions)
     __shared__ uint32_t qxy[CQ];
     __shared__ uint8_t qmv[CQ];
-    // head/tail of the 32 HBM bucket rings live in two VGPRs: lane i holds bucket i
-    // (read with v_readlane, updated with a lane-select: no memory traffic on the critical path)
-    int vhead = 0, vtail = 0;
-#define HEAD(bb) __builtin_amdgcn_readlane(vhead, (bb))
-#define TAIL(bb) __builtin_amdgcn_readlane(vtail, (bb))
+    // head/tail of the 32 HBM bucket rings: lanes that insert take their slot with one LDS atomic add
+    // on the tail (no ballot loop per f class); the pop side reads them with plain ds_reads
+    __shared__ int s_head[NBUCKET];
+    __shared__ int s_tail[NBUCKET];
+#define HEAD(bb) __hip_atomic_load(&s_head[(bb)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#define TAIL(bb) __hip_atomic_load(&s_tail[(bb)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     const int q = a.q0 + slot;
@@ -139,6 +177,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     const int ck1 = d < 2 ? 2 : 1, ce1 = (int)((0x7554u >> (4 * (d & 3))) & 7u);   // E:(S,SE) W:(S,SW) S:(W,SW) N:(W,NW)
     const bool p_cond = d < 4;
 
+    if (lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
     int fcur = octile(sx, sy, gx, gy);
     if (lane == 0) {
         __hip_atomic_store(&g[s], etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
@@ -148,14 +187,13 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int lh = 0, lt = 1;  // LDS ring of the current f (wave-uniform)
 
-    bool found = false, overflow = false;
+    bool found = false, overflow = false, ovf = false;
     int nexp = 0, niter = 0;
 #ifdef ASTAR_STAMPS
     unsigned long long st_pop = 0, st_mem = 0, st_rest = 0;
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
     dbg_t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (;;) {
         const int b = fcur & 31;
@@ -219,7 +257,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         valid[k] = valid[k] && (gv[k] & ~gmask) == etag && (int)(gc[k] + octile(cx[k], cy[k], gx, gy)) == fcur;
                         mv[k] = mm[k] & ~prune_always((int)de[k]);
                     }
-                    vhead = lane == b ? hd + n : vhead;
+                    if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
 #ifdef ASTAR_STAMPS
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -228,16 +266,28 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                 // ---- relax: every lane handles move d of its node; all groups' memory operations first ----
                 uint32_t old[KM], nmv[KM];
                 bool legal[KM];
+                if constexpr (KM == 1) {
+                    // a single conditional block costs nothing extra
+                    old[0] = 0; nmv[0] = 0;
+                    legal[0] = valid[0] && ((mv[0] >> d) & 1);
+                    if (legal[0]) {
+                        const int nidx = cy[0] * W + cx[0] + moff;
+                        old[0] = __hip_atomic_fetch_min(&g[nidx], etag | (gc[0] + mw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        nmv[0] = a.moves[nidx];
+                    }
+                } else {
+                    uint32_t* ad[KM];
+                    uint32_t dv[KM];
 #pragma unroll
-                for (int k = 0; k < KM; ++k) {
-                    // Issued unconditionally: a divergent `if` around each atomic makes the compiler drain
-                    // vmcnt before every one of them (8 dependent round trips per step).  Lanes without a
-                    // legal move send the no-op operand 0xFFFFFFFF to a harmless cell of the slot.
-                    legal[k] = valid[k] && ((mv[k] >> d) & 1);
-                    const int nidx = legal[k] ? cy[k] * W + cx[k] + moff : lane;
-                    old[k] = __hip_atomic_fetch_min(&g[nidx], legal[k] ? (etag | (gc[k] + mw)) : 0xFFFFFFFFu, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    nmv[k] = a.moves[nidx];
+                    for (int k = 0; k < KM; ++k) {
+                        legal[k] = valid[k] && ((mv[k] >> d) & 1);
+                        const int nidx = legal[k] ? cy[k] * W + cx[k] + moff : 0;
+                        ad[k] = &g[nidx];
+                        dv[k] = legal[k] ? (etag | (gc[k] + mw)) : 0xFFFFFFFFu;
+                        old[k] = 0;
+                        nmv[k] = a.moves[nidx];   // plain loads: unconditional is harmless
+                    }
+                    masked_atomic_min2(ad, dv, old);
                 }
 #ifdef ASTAR_STAMPS
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -256,30 +306,27 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     uint32_t prune = p_always;
                     if (p_cond) prune |= (((mv[k] >> ce0) & 1u) << ck0) | (((mv[k] >> ce1) & 1u) << ck1);
                     const uint32_t smv = nmv[k] & ~prune;
-                    unsigned long long rem = __ballot(imp);
-                    while (rem) {
-                        const int leader = __ffsll((long long)rem) - 1;
-                        const int v = __builtin_amdgcn_readlane(df, leader);
-                        const bool mine = imp && df == v;
-                        const unsigned long long m = __ballot(mine);
-                        const int cnt = __popcll(m);
-                        const int rank = __popcll(m & lt_mask);
-                        if (v == 0 && lt - lh + cnt <= CQ) {
-                            if (mine) {
+                    // same-f successors: consecutive slots of the LDS ring by ballot rank
+                    const bool same = imp && df == 0;
+                    const unsigned long long m0 = __ballot(same);
+                    bool spill = false;
+                    if (m0) {
+                        const int cnt = __popcll(m0);
+                        if (lt - lh + cnt <= CQ) {
+                            if (same) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
                                 qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
                                 qmv[(lt + rank) & (CQ - 1)] = (uint8_t)smv;
                             }
                             lt += cnt;
-                        } else {
-                            const int bb = (fcur + v) & 31;
-                            const int base = TAIL(bb);
-                            if (base + cnt - HEAD(bb) > cap) overflow = true;
-                            else {
-                                if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | d << 13 | nx);
-                                vtail = lane == bb ? base + cnt : vtail;
-                            }
-                        }
-                        rem &= ~m;
+                        } else spill = true;   // ring full: park them in the HBM bucket of this level
+                    }
+                    // other levels: one LDS atomic per inserting lane hands out its slot in the HBM ring
+                    if (imp && (df != 0 || spill)) {
+                        const int bb = (fcur + df) & 31;
+                        const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (pos - HEAD(bb) >= cap) ovf = true;
+                        else bk[(size_t)bb * cap + (pos & capm)] = (uint32_t)(ny << 16 | d << 13 | nx);
                     }
                 }
 #ifdef ASTAR_STAMPS
@@ -314,22 +361,25 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     gc = gv & gmask;
                     valid = valid && (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
                     mv = mm & ~prune_always((int)de);
-                    vhead = lane == b ? hd + n : vhead;
+                    if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 if (!valid) mv = 0;
                 const int c = cy * W + cx;
                 nexp += __popcll(__ballot(valid));
                 if (__ballot(valid && c == t)) found = true;
                 const int off8[8] = {1, -1, W, -W, W + 1, W - 1, -W + 1, -W - 1};
-                uint32_t old[8], nmv[8];
+                uint32_t old[8], nmv[8], dv[8];
+                uint32_t* ad[8];
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {   // unconditional issue (see the note in step())
+                for (int dd = 0; dd < 8; ++dd) {
                     const bool lg = (mv >> dd) & 1;
-                    const int nidx = lg ? c + off8[dd] : lane;
-                    old[dd] = __hip_atomic_fetch_min(&g[nidx], lg ? (etag | (gc + (dd < 4 ? 10u : 14u))) : 0xFFFFFFFFu, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                    nmv[dd] = a.moves[nidx];
+                    const int nidx = lg ? c + off8[dd] : 0;
+                    ad[dd] = &g[nidx];
+                    dv[dd] = lg ? (etag | (gc + (dd < 4 ? 10u : 14u))) : 0xFFFFFFFFu;
+                    old[dd] = 0;
+                    nmv[dd] = a.moves[nidx];   // plain loads: unconditional is harmless
                 }
+                masked_atomic_min8(ad, dv, old);
 #pragma unroll
                 for (int dd = 0; dd < 8; ++dd) {
                     const uint32_t ng = gc + (dd < 4 ? 10u : 14u);
@@ -342,42 +392,39 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         prune |= (((mv >> e0) & 1u) << k0) | (((mv >> e1) & 1u) << k1);
                     }
                     const uint32_t smv = nmv[dd] & ~prune;
-                    unsigned long long rem = __ballot(imp);
-                    while (rem) {
-                        const int leader = __ffsll((long long)rem) - 1;
-                        const int v = __builtin_amdgcn_readlane(df, leader);
-                        const bool mine = imp && df == v;
-                        const unsigned long long m = __ballot(mine);
-                        const int cnt = __popcll(m);
-                        const int rank = __popcll(m & lt_mask);
-                        if (v == 0 && lt - lh + cnt <= CQ) {
-                            if (mine) {
+                    // same-f successors: consecutive slots of the LDS ring by ballot rank
+                    const bool same = imp && df == 0;
+                    const unsigned long long m0 = __ballot(same);
+                    bool spill = false;
+                    if (m0) {
+                        const int cnt = __popcll(m0);
+                        if (lt - lh + cnt <= CQ) {
+                            if (same) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
                                 qxy[(lt + rank) & (CQ - 1)] = (uint32_t)(ny << 16 | nx);
                                 qmv[(lt + rank) & (CQ - 1)] = (uint8_t)smv;
                             }
                             lt += cnt;
-                        } else {
-                            const int bb = (fcur + v) & 31;
-                            const int base = TAIL(bb);
-                            if (base + cnt - HEAD(bb) > cap) overflow = true;
-                            else {
-                                if (mine) bk[(size_t)bb * cap + ((base + rank) & capm)] = (uint32_t)(ny << 16 | dd << 13 | nx);
-                                vtail = lane == bb ? base + cnt : vtail;
-                            }
-                        }
-                        rem &= ~m;
+                        } else spill = true;   // ring full: park them in the HBM bucket of this level
+                    }
+                    // other levels: one LDS atomic per inserting lane hands out its slot in the HBM ring
+                    if (imp && (df != 0 || spill)) {
+                        const int bb = (fcur + df) & 31;
+                        const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (pos - HEAD(bb) >= cap) ovf = true;
+                        else bk[(size_t)bb * cap + (pos & capm)] = (uint32_t)(ny << 16 | dd << 13 | nx);
                     }
                 }
             };
             if (K == 1) step(std::integral_constant<int, 1>{});
             else if (K == 2) step(std::integral_constant<int, 2>{});
             else step_wide();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (overflow) break;
+            __builtin_amdgcn_wave_barrier();
+            if (__ballot(ovf)) { overflow = true; break; }
         }
         if (overflow || found) break;
         // level fcur is exhausted: advance to the next non-empty bucket
-        const uint32_t nonempty = (uint32_t)__ballot(vhead != vtail);   // bit i = bucket i (lanes >= 32 hold 0 == 0)
+        const uint32_t nonempty = (uint32_t)__ballot(lane < NBUCKET && HEAD(lane & 31) != TAIL(lane & 31));   // bit i = bucket i
         if (nonempty == 0) break;  // open list empty: no path
         const int r0 = (fcur + 1) & 31;
         const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
