@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the "
+                         "multi-rank control flow with several ranks on one GPU: results are gathered through host copies)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -75,11 +78,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
     dist = None
+    ngpu = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local_rank = local_rank % max(ngpu, 1)     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import sea_current_amd as sc
     from sea_current_amd import synth, shard
@@ -91,6 +100,8 @@ def main():
     q0, q1 = shard.rank_range(Qtot, world, rank)
 
     def fence():
+        for c in slot_ctx:
+            c.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -152,8 +163,14 @@ def main():
             for i in range(nsteps):
                 done[i].wait()
                 if world > 1 and not errors:
-                    shard.allgather_paths(outs[i % depth], gathered[i % depth], dist)
-                    torch.cuda.current_stream().synchronize()
+                    if args.backend == "nccl":
+                        shard.allgather_paths(outs[i % depth], gathered[i % depth], dist)
+                        torch.cuda.current_stream().synchronize()
+                    else:  # gloo rehearsal: gather through host memory
+                        host_out = {k: v.cpu() for k, v in outs[i % depth].items()}
+                        host_all = shard.allgather_paths(host_out, shard.alloc_gather(host_out, world), dist)
+                        for k in host_all:
+                            gathered[i % depth][k].copy_(host_all[k])
                 released[i].set()
             for t in ths:
                 t.join()
@@ -169,9 +186,13 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            # every rank must now hold every rank's results, in query order
+            gl = gathered[(steps - 1) % depth]["len"].cpu().numpy()
+            mine = outs[(steps - 1) % depth]["len"].cpu().numpy()
+            assert gl.shape[0] == Qtot and np.array_equal(gl[q0:q1], mine), "gather of result paths is inconsistent"
         step_kernels = {}
         nslot0 = max(1, len(range(0, steps, depth)))   # timing is collected on slot 0 only
         for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR)):

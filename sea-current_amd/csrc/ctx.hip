@@ -42,7 +42,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
     free_scratch(&ctx->buckets); free_scratch(&ctx->qstats);
@@ -116,6 +116,16 @@ void sc_time_end(sc_ctx* ctx, int token) {
     (void)hipEventRecord(ctx->pending[token].b, ctx->stream);
 }
 
+// end of bracket `token` and begin of a bracket for `kid` with ONE event record (back-to-back kernels)
+int sc_time_chain(sc_ctx* ctx, int token, int kid) {
+    if (token < 0) return -1;
+    (void)hipEventRecord(ctx->pending[token].b, ctx->stream);
+    sc_ctx::pending_ev p{kid, ctx->pending[token].b, get_event(ctx)};
+    p.shared_a = true;
+    ctx->pending.push_back(p);
+    return (int)ctx->pending.size() - 1;
+}
+
 static void drain_timing(sc_ctx* ctx) {
     for (auto& p : ctx->pending) {
         float ms = 0.f;
@@ -123,7 +133,7 @@ static void drain_timing(sc_ctx* ctx) {
             ctx->t_ms[p.kid] += ms;
             ctx->t_n[p.kid] += 1;
         }
-        ctx->ev_pool.push_back(p.a);
+        if (!p.shared_a) ctx->ev_pool.push_back(p.a);
         ctx->ev_pool.push_back(p.b);
     }
     ctx->pending.clear();

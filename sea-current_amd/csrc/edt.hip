@@ -386,31 +386,49 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     for (int q = threadIdx.x; q < WP / 2; q += WAVES * 64) {
         uint32_t nw[2];
         int up[2], dn[2];
+        {
+            // first round: the band's own word and the 4 bands above / below, for both columns, as 18
+            // independent loads (one memory round trip); further rounds only for columns still unresolved
+            uint32_t w[2], wu[2][4], wd[2][4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int x = 2 * q + c;
-            uint32_t w = 0;
-            up[c] = EDT_G_INF; dn[c] = EDT_G_INF;
-            if (x < W) {
-                w = cb[(size_t)b * W + x];
-                for (int base = b - 1; base >= 0 && up[c] == EDT_G_INF; base -= 4) {
-                    uint32_t ww[4];
+            for (int c = 0; c < 2; ++c) {
+                const int x = 2 * q + c;
+                w[c] = x < W ? cb[(size_t)b * W + x] : 0u;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) ww[t] = base - t >= 0 ? cb[(size_t)(base - t) * W + x] : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (up[c] == EDT_G_INF && ww[t]) up[c] = (b - (base - t)) * 32 - (31 - __clz((int)ww[t]));
-                }
-                for (int base = b + 1; base < nb && dn[c] == EDT_G_INF; base += 4) {
-                    uint32_t ww[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) ww[t] = base + t < nb ? cb[(size_t)(base + t) * W + x] : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (dn[c] == EDT_G_INF && ww[t]) dn[c] = ((base + t) - b) * 32 + (__ffs((int)ww[t]) - 1) - 31;
+                for (int t = 0; t < 4; ++t) {
+                    wu[c][t] = (x < W && b - 1 - t >= 0) ? cb[(size_t)(b - 1 - t) * W + x] : 0u;
+                    wd[c][t] = (x < W && b + 1 + t < nb) ? cb[(size_t)(b + 1 + t) * W + x] : 0u;
                 }
             }
-            nw[c] = ~w;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int x = 2 * q + c;
+                up[c] = EDT_G_INF; dn[c] = EDT_G_INF;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (up[c] == EDT_G_INF && wu[c][t]) up[c] = (t + 1) * 32 - (31 - __clz((int)wu[c][t]));
+                    if (dn[c] == EDT_G_INF && wd[c][t]) dn[c] = (t + 1) * 32 + (__ffs((int)wd[c][t]) - 1) - 31;
+                }
+                if (x < W) {
+                    for (int base = b - 5; base >= 0 && up[c] == EDT_G_INF; base -= 4) {
+                        uint32_t ww[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ww[t] = base - t >= 0 ? cb[(size_t)(base - t) * W + x] : 0u;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (up[c] == EDT_G_INF && ww[t]) up[c] = (b - (base - t)) * 32 - (31 - __clz((int)ww[t]));
+                    }
+                    for (int base = b + 5; base < nb && dn[c] == EDT_G_INF; base += 4) {
+                        uint32_t ww[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ww[t] = base + t < nb ? cb[(size_t)(base + t) * W + x] : 0u;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (dn[c] == EDT_G_INF && ww[t]) dn[c] = ((base + t) - b) * 32 + (__ffs((int)ww[t]) - 1) - 31;
+                    }
+                }
+                nw[c] = ~w[c];
+            }
         }
         // top-down: gu = rows to the nearest obstacle at or above; stored clamped at 255
         uint32_t GU[32];
@@ -570,7 +588,8 @@ static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, in
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    int tk = sc_time_begin(ctx, SC_K_EDT_BAND);
+    int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+    ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_g8_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream,
                        colbits, W, H, nb, d2);
     sc_time_end(ctx, tk);
@@ -596,7 +615,8 @@ static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int n
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    int tk = sc_time_begin(ctx, SC_K_EDT_BAND);
+    int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+    ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(256), lds, ctx->stream,
                        colbits, W, H, nb, d2);
     sc_time_end(ctx, tk);
@@ -628,10 +648,9 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
         dim3 grid((W + 255) / 256, nb, batch);
         hipLaunchKernelGGL(edt_colbits_generic_kernel, grid, dim3(256), 0, ctx->stream, occ, W, H, nb, colbits);
     }
-    sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
-
-    if (skip_band) return SC_OK;
+    if (skip_band) { sc_time_end(ctx, tk); return SC_OK; }
+    ctx->edt_chain_token = tk;
     // pixels per lane: smallest power of two with 64 * PPL >= W
     if (W <= 128) return launch_band_ppl<2>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 256) return launch_band_ppl<4>(ctx, colbits, W, H, nb, batch, d2);

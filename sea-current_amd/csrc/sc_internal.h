@@ -21,7 +21,7 @@ struct sc_ctx {
     char err[256] = {0};
     // timing
     int timing = 0;
-    struct pending_ev { int kid; hipEvent_t a, b; };
+    struct pending_ev { int kid; hipEvent_t a, b; bool shared_a = false; };
     std::vector<pending_ev> pending;
     std::vector<hipEvent_t> ev_pool;
     double t_ms[SC_K_COUNT] = {0};
@@ -36,6 +36,7 @@ struct sc_ctx {
     int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
     int last_Q = 0;
+    int edt_chain_token = -1;       // timing: colbits' end event doubles as band's start event
     uint32_t astar_epoch = 0;       // descending epoch tag of the g slots (0: slots must be cleared)
     int astar_shift = 0;            // bits of g below the tag
     uint32_t astar_last_tag = 0, astar_last_mask = 0xFFFFFFFFu;
@@ -56,6 +57,7 @@ int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes);
 // RAII-free timing bracket: t = sc_time_begin(ctx, kid); launch...; sc_time_end(ctx, t)
 int sc_time_begin(sc_ctx* ctx, int kid);
 void sc_time_end(sc_ctx* ctx, int token);
+int sc_time_chain(sc_ctx* ctx, int token, int kid);
 
 // kernels' host launchers (defined in the respective .hip files)
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
