@@ -58,7 +58,9 @@ typedef enum {
     SC_K_ASTAR = 3,       /* batched A*: one wavefront per query */
     SC_K_TOPPRA = 4,      /* batched TOPP-RA: computeParams + backward + forward sweep */
     SC_K_TOPPRA_SAMPLE = 5,
-    SC_K_COUNT = 6
+    SC_K_BEZIER = 6,      /* tangents + control points, curve evaluation */
+    SC_K_ARCLENGTH = 7,   /* GL-32 arclength tables */
+    SC_K_COUNT = 8
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -167,6 +169,28 @@ int sc_toppra_sample_batch_host(sc_ctx* ctx, int P, int dof, int N,
                                 const double* p0, const double* p1, const double* v0, const double* v1,
                                 const double* x, const double* t, double dt, int max_len,
                                 float* pos, float* vel, float* acc, double* times, int32_t* length);
+
+/* ---- path smoothing and arclength ----------------
+ * P paths of up to n_max waypoints (float [P][n_max][2], npts [P] valid counts).
+ * ctrl: float [P][n_max-1][4][2], the cubic Bezier of every leg (zeros past a
+ * path's last leg).  lines: float [nlines][4] obstacle edges (x0,y0,x1,y1) used
+ * to shrink tangents; start_angle NaN = along the first leg.  Takes over
+ * bezier_spline::from_path (sea_current.hpp:599-683) with calc_start_tangent /
+ * calc_tangent / calc_end_tangent (:343-377) and shrink_tangent (:575-596). */
+int sc_bezier_from_path_batch(sc_ctx* ctx, const float* path, const int32_t* npts, int P, int n_max, float start_angle,
+                              const float* lines, int nlines, float* ctrl);
+int sc_bezier_from_path_batch_host(sc_ctx* ctx, const float* path, const int32_t* npts, int P, int n_max, float start_angle,
+                                   const float* lines, int nlines, float* ctrl);
+/* Point (order 0), hodograph (1) or second derivative (2) of segment seg[i] (index
+ * into ctrl viewed as [S][4][2]) at parameter t[i]; out float [M][2].  Takes over
+ * bezier_spline::bezier_curve (:700-763) and ::hodograph (:1041-1053). */
+int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_t* seg, const float* t, int M, int order, float* out);
+/* bezier_spline::arclength (:767-896): 32-point Gauss-Legendre on nsub (= 1/precision)
+ * sub-intervals of every segment.  cum float [S][nsub+1] cumulative length at
+ * t = k/nsub, seg_len float [S] (the reference's arclength_data: segments, and
+ * arclength = sum of seg_len over a path). */
+int sc_bezier_arclength_batch(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len);
+int sc_bezier_arclength_batch_host(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len);
 
 #ifdef __cplusplus
 }

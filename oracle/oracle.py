@@ -32,6 +32,7 @@ def lib():
         _LIB.sco_astar.restype = C.c_int
         _LIB.sco_toppra.restype = C.c_int
         _LIB.sco_toppra_sample.restype = C.c_int
+        _LIB.sco_bezier_arclength.restype = C.c_double
     return _LIB
 
 
@@ -122,3 +123,32 @@ def toppra_sample(p0, p1, v0, v1, x, t, dt, max_len=None):
                                 _p(acc, C.c_float), _p(times, d))
     m = min(n, max_len)
     return dict(length=n, pos=pos[:, :m], vel=vel[:, :m], acc=acc[:, :m], time=times[:m])
+
+
+def bezier_from_path(path, start_angle=float("nan"), lines=None):
+    """path [n,2] float32 -> ctrl [n-1,4,2] float32 (sea_current.hpp:599-683)."""
+    path = np.ascontiguousarray(path, dtype=np.float32)
+    n = path.shape[0]
+    lines = np.zeros((0, 4), np.float32) if lines is None else np.ascontiguousarray(lines, dtype=np.float32)
+    ctrl = np.zeros((n - 1, 4, 2), dtype=np.float32)
+    lib().sco_bezier_from_path(_p(path, C.c_float), C.c_int(n), C.c_float(start_angle), _p(lines, C.c_float),
+                               C.c_int(lines.shape[0]), _p(ctrl, C.c_float))
+    return ctrl
+
+
+def bezier_eval(ctrl, seg, t, order=0):
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    seg = np.ascontiguousarray(seg, dtype=np.int32)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    out = np.zeros((t.shape[0], 2))
+    lib().sco_bezier_eval(_p(ctrl, C.c_float), _p(seg, C.c_int32), _p(t, C.c_double), C.c_int(t.shape[0]), C.c_int(order),
+                          _p(out, C.c_double))
+    return out
+
+
+def bezier_arclength(ctrl, nsub=100):
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    nseg = ctrl.shape[0]
+    cum = np.zeros((nseg, nsub + 1))
+    total = lib().sco_bezier_arclength(_p(ctrl, C.c_float), C.c_int(nseg), C.c_int(nsub), _p(cum, C.c_double))
+    return total, cum

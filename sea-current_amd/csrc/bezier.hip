@@ -1,0 +1,216 @@
+// bezier.hip -- batched path smoothing and arclength (gfx950).  SURVEY.md 8f rank 1-2 ("next" rows).
+//
+// Takes over bezier_spline::from_path (sea_current.hpp:599-683: Lau09 tangent heuristics :343-377,
+// shrink_tangent :575-596), the cubic Bezier / hodograph evaluation (:700-763, :1041-1053) and
+// bezier_spline::arclength (:767-896: 32-point Gauss-Legendre on 1/precision sub-intervals per segment).
+// The maths is restated in oracle/bezier_oracle.c, which is pinned to examples/output.json (total
+// arclength 5e-8 relative, cumulative tables 2e-6 absolute).  Curves are evaluated in Bernstein form
+// (the reference evaluates the same polynomial through its Bernstein-Fourier form) in fp64.
+//
+// Parallelism: one thread per (path, waypoint) for the tangents; one wavefront per segment for the
+// arclength (lanes over sub-intervals, 32 quadrature points each, cumulative table by a wave scan);
+// one thread per sample for evaluation.  All three are tiny next to EDT and A*.
+#include "sc_internal.h"
+
+#include <cmath>
+
+struct seg4 { float lx0, ly0, lx1, ly1; };
+
+__device__ __forceinline__ bool seg_hit(double p1x, double p1y, double p2x, double p2y, const float* l, double* ix, double* iy) {
+    const double rx = p2x - p1x, ry = p2y - p1y, sx = (double)l[2] - l[0], sy = (double)l[3] - l[1];
+    const double den = rx * sy - ry * sx;
+    if (den == 0.0) return false;
+    const double qx = l[0] - p1x, qy = l[1] - p1y;
+    const double t = (qx * sy - qy * sx) / den, u = (qx * ry - qy * rx) / den;
+    if (t < 0 || t > 1 || u < 0 || u > 1) return false;
+    *ix = p1x + t * rx; *iy = p1y + t * ry;
+    return true;
+}
+
+__device__ __forceinline__ void shrink(double& tx, double& ty, double wx, double wy, const float* lines, int nlines) {
+    for (int i = 0; i < nlines; ++i) {
+        double ix, iy;
+        if (seg_hit(wx + tx, wy + ty, wx, wy, lines + 4 * i, &ix, &iy)) { tx = ix - wx; ty = iy - wy; }
+        if (seg_hit(wx - tx, wy - ty, wx, wy, lines + 4 * i, &ix, &iy)) { tx = wx - ix; ty = wy - iy; }
+    }
+}
+
+// tangent of waypoint i of path p -> tang [P][n_max][2]
+__global__ void __launch_bounds__(256)
+bezier_tangent_kernel(const float* __restrict__ path, const int32_t* __restrict__ npts, int P, int n_max, float start_angle,
+                      const float* __restrict__ lines, int nlines, double* __restrict__ tang) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= P * n_max) return;
+    const int p = gid / n_max, i = gid % n_max;
+    const int n = npts[p];
+    if (i >= n || n < 2) return;
+    const float* w = path + (size_t)p * n_max * 2;
+    auto X = [&](int k) { return (double)w[2 * k]; };
+    auto Y = [&](int k) { return (double)w[2 * k + 1]; };
+    double tx, ty;
+    if (i == 0) {
+        double th = start_angle;
+        if (isnan(start_angle)) th = atan2(Y(1) - Y(0), X(1) - X(0));
+        const double m = 0.5 * hypot(X(1) - X(0), Y(1) - Y(0));
+        tx = m * cos(th); ty = m * sin(th);
+    } else if (i == n - 1) {
+        const double ex = X(n - 1) - X(n - 2), ey = Y(n - 1) - Y(n - 2), el = hypot(ex, ey);
+        tx = 0.5 * ex; ty = 0.5 * ey;   // 0.5 * |e| * e / |e|
+        (void)el;
+    } else {
+        const double ux = X(i - 1) - X(i), uy = Y(i - 1) - Y(i), vx = X(i + 1) - X(i), vy = Y(i + 1) - Y(i);
+        const double theta = acos((ux * vx + uy * vy) / (hypot(ux, uy) * hypot(vx, vy))) / 2;
+        const double off = atan2(uy, ux), toff = atan2(vy, vx);
+        const int mult = (toff - off < 0) ? -1 : 1;
+        double lx = sin(off + mult * theta), ly = -cos(off + mult * theta);
+        const double ll = hypot(lx, ly);
+        lx /= ll; ly /= ll;
+        const int mult2 = hypot(X(i) + lx - X(i + 1), Y(i) + ly - Y(i + 1)) < hypot(X(i) - lx - X(i + 1), Y(i) - ly - Y(i + 1)) ? 1 : -1;
+        const double mag = 0.5 * fmin(hypot(ux, uy), hypot(vx, vy));
+        tx = mag * mult2 * lx; ty = mag * mult2 * ly;
+    }
+    shrink(tx, ty, X(i), Y(i), lines, nlines);
+    tang[((size_t)p * n_max + i) * 2] = tx;
+    tang[((size_t)p * n_max + i) * 2 + 1] = ty;
+}
+
+// control points of leg i of path p -> ctrl [P][n_max-1][4][2]
+__global__ void __launch_bounds__(256)
+bezier_ctrl_kernel(const float* __restrict__ path, const int32_t* __restrict__ npts, int P, int n_max,
+                   const double* __restrict__ tang, float* __restrict__ ctrl) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= P * (n_max - 1)) return;
+    const int p = gid / (n_max - 1), i = gid % (n_max - 1);
+    float* c = ctrl + ((size_t)p * (n_max - 1) + i) * 8;
+    if (i >= npts[p] - 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = 0.f;
+        return;
+    }
+    const float* w = path + ((size_t)p * n_max + i) * 2;
+    const double* t = tang + ((size_t)p * n_max + i) * 2;
+    c[0] = w[0]; c[1] = w[1];
+    c[2] = (float)((double)w[0] + t[0]); c[3] = (float)((double)w[1] + t[1]);
+    c[4] = (float)((double)w[2] - t[2]); c[5] = (float)((double)w[3] - t[3]);
+    c[6] = w[2]; c[7] = w[3];
+}
+
+__device__ __forceinline__ void bez_eval(const float* c, double s, int order, double& ox, double& oy) {
+    const double r = 1 - s;
+    double o[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double p0 = c[a], p1 = c[2 + a], p2 = c[4 + a], p3 = c[6 + a];
+        if (order == 0) o[a] = r * r * r * p0 + 3 * r * r * s * p1 + 3 * r * s * s * p2 + s * s * s * p3;
+        else if (order == 1) o[a] = 3 * (r * r * (p1 - p0) + 2 * r * s * (p2 - p1) + s * s * (p3 - p2));
+        else o[a] = 6 * (r * (p2 - 2 * p1 + p0) + s * (p3 - 2 * p2 + p1));
+    }
+    ox = o[0]; oy = o[1];
+}
+
+__global__ void __launch_bounds__(256)
+bezier_eval_kernel(const float* __restrict__ ctrl, const int32_t* __restrict__ seg, const float* __restrict__ t, int M, int order,
+                   float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double x, y;
+    bez_eval(ctrl + (size_t)seg[i] * 8, (double)t[i], order, x, y);
+    out[2 * i] = (float)x; out[2 * i + 1] = (float)y;
+}
+
+// one wavefront per segment; gl = 32 nodes then 32 weights; cum [S][nsub+1], seg_len [S]
+__global__ void __launch_bounds__(64)
+bezier_arclength_kernel(const float* __restrict__ ctrl, int S, int nsub, const double* __restrict__ gl, float* __restrict__ cum,
+                        float* __restrict__ seg_len) {
+    extern __shared__ double sub[];   // [nsub] arclength of each sub-interval
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const float* c = ctrl + (size_t)s * 8;
+    for (int k = lane; k < nsub; k += 64) {
+        const double a = (double)k / nsub, b = (double)(k + 1) / nsub;
+        double sum = 0;
+        for (int i = 0; i < 32; ++i) {
+            double dx, dy;
+            bez_eval(c, 0.5 * (b - a) * gl[i] + 0.5 * (b + a), 1, dx, dy);
+            sum += gl[32 + i] * sqrt(dx * dx + dy * dy);
+        }
+        sub[k] = sum * 0.5 * (b - a);
+    }
+    __syncthreads();
+    // cumulative table: each lane owns a contiguous chunk, wave scan of the chunk sums
+    const int chunk = (nsub + 63) / 64;
+    const int k0 = lane * chunk, k1 = min(nsub, k0 + chunk);
+    double local = 0;
+    for (int k = k0; k < k1; ++k) local += sub[k];
+    double incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    double run = incl - local;
+    float* out = cum + (size_t)s * (nsub + 1);
+    if (lane == 0) out[0] = 0.f;
+    for (int k = k0; k < k1; ++k) { run += sub[k]; out[k + 1] = (float)run; }
+    if (lane == 63) seg_len[s] = (float)incl;
+}
+
+static void gl32_host(double* x, double* w) {
+    const int N = 32;
+    for (int i = 0; i < N; ++i) {
+        double z = std::cos(std::acos(-1.0) * (i + 0.75) / (N + 0.5)), pp = 0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1, p2 = 0;
+            for (int j = 1; j <= N; ++j) { const double p3 = p2; p2 = p1; p1 = ((2.0 * j - 1) * z * p2 - (j - 1.0) * p3) / j; }
+            pp = N * (z * p1 - p2) / (z * z - 1);
+            const double z1 = z;
+            z = z1 - p1 / pp;
+            if (std::fabs(z - z1) < 1e-16) break;
+        }
+        x[i] = z; w[i] = 2 / ((1 - z * z) * pp * pp);
+    }
+}
+
+extern "C" int sc_bezier_from_path_batch(sc_ctx* ctx, const float* path, const int32_t* npts, int P, int n_max, float start_angle,
+                                         const float* lines, int nlines, float* ctrl) {
+    if (!ctx || !path || !npts || !ctrl || P <= 0 || n_max < 2 || nlines < 0 || (nlines > 0 && !lines)) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int r = sc_scratch_reserve(ctx, &ctx->bez_tang, (size_t)P * n_max * 2 * sizeof(double));
+    if (r != SC_OK) return r;
+    double* tang = (double*)ctx->bez_tang.p;
+    int tk = sc_time_begin(ctx, SC_K_BEZIER);
+    hipLaunchKernelGGL(bezier_tangent_kernel, dim3((P * n_max + 255) / 256), dim3(256), 0, ctx->stream, path, npts, P, n_max,
+                       start_angle, lines, nlines, tang);
+    hipLaunchKernelGGL(bezier_ctrl_kernel, dim3((P * (n_max - 1) + 255) / 256), dim3(256), 0, ctx->stream, path, npts, P, n_max,
+                       tang, ctrl);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_t* seg, const float* t, int M, int order, float* out) {
+    if (!ctx || !ctrl || !seg || !t || !out || M <= 0 || order < 0 || order > 2) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int tk = sc_time_begin(ctx, SC_K_BEZIER);
+    hipLaunchKernelGGL(bezier_eval_kernel, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctrl, seg, t, M, order, out);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_bezier_arclength_batch(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len) {
+    if (!ctx || !ctrl || !cum || !seg_len || S <= 0 || nsub <= 0 || nsub > 4096) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->bez_gl.p) {
+        int r = sc_scratch_reserve(ctx, &ctx->bez_gl, 64 * sizeof(double));
+        if (r != SC_OK) return r;
+        double h[64];
+        gl32_host(h, h + 32);
+        SC_HIP(ctx, hipMemcpy(ctx->bez_gl.p, h, sizeof(h), hipMemcpyHostToDevice));
+    }
+    int tk = sc_time_begin(ctx, SC_K_ARCLENGTH);
+    hipLaunchKernelGGL(bezier_arclength_kernel, dim3(S), dim3(64), (size_t)nsub * sizeof(double), ctx->stream, ctrl, S, nsub,
+                       (const double*)ctx->bez_gl.p, cum, seg_len);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}

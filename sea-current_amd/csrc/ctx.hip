@@ -45,7 +45,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
-    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats);
+    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -266,5 +266,36 @@ extern "C" int sc_toppra_sample_batch_host(sc_ctx* ctx, int P, int dof, int N,
     SC_HIP(ctx, hipMemcpyAsync(acc, b + oacc, fb, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(times, b + otim, (size_t)P * max_len * 8, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(length, b + olen, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_bezier_from_path_batch_host(sc_ctx* ctx, const float* path, const int32_t* npts, int P, int n_max, float start_angle,
+                                              const float* lines, int nlines, float* ctrl) {
+    if (!ctx || !path || !npts || !ctrl || P <= 0 || n_max < 2 || nlines < 0 || (nlines > 0 && !lines)) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pb = (size_t)P * n_max * 2 * 4, nb = (size_t)P * 4, lb = (size_t)nlines * 16, cb = (size_t)P * (n_max - 1) * 32;
+    STAGE(2, pb + nb + lb + cb + 64);
+    char* b = (char*)ctx->staging[2].p;
+    SC_HIP(ctx, hipMemcpyAsync(b, path, pb, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + pb, npts, nb, hipMemcpyHostToDevice, ctx->stream));
+    if (lb) SC_HIP(ctx, hipMemcpyAsync(b + pb + nb, lines, lb, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_from_path_batch(ctx, (const float*)b, (const int32_t*)(b + pb), P, n_max, start_angle,
+                                      lb ? (const float*)(b + pb + nb) : nullptr, nlines, (float*)(b + pb + nb + lb));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(ctrl, b + pb + nb + lb, cb, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_bezier_arclength_batch_host(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len) {
+    if (!ctx || !ctrl || !cum || !seg_len || S <= 0 || nsub <= 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cb = (size_t)S * 32, ub = (size_t)S * (nsub + 1) * 4, sb = (size_t)S * 4;
+    STAGE(3, cb + ub + sb);
+    char* b = (char*)ctx->staging[3].p;
+    SC_HIP(ctx, hipMemcpyAsync(b, ctrl, cb, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_arclength_batch(ctx, (const float*)b, S, nsub, (float*)(b + cb), (float*)(b + cb + ub));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(cum, b + cb, ub, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(seg_len, b + cb + ub, sb, hipMemcpyDeviceToHost, ctx->stream));
     return sc_ctx_synchronize(ctx);
 }

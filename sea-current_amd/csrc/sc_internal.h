@@ -32,6 +32,8 @@ struct sc_ctx {
     sc_scratch gslots;      // A*: uint32 [S][cells]
     sc_scratch buckets;     // A*: uint32 [S][32][cap]
     sc_scratch qstats;      // A*: int32 expanded[Q] + flags
+    sc_scratch bez_tang;    // Bezier: double [P][n_max][2] tangents
+    sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed

@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE = range(6)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH = range(8)
 
 _lib = None
 
@@ -62,6 +62,11 @@ _SIGNATURES = {
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_sample_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
     "sc_toppra_sample_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+    "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
+    "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
+    "sc_bezier_eval_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sc_bezier_arclength_batch_host": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sc_bezier_arclength_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -239,6 +244,33 @@ class Context:
                                                 _ptr(out["acc"]), _ptr(out["time"]), _ptr(out["length"])),
                  "sc_toppra_sample_batch")
         return out
+
+    def bezier_from_path(self, path, npts, start_angle=float("nan"), lines=None):
+        """path float32 [P,n_max,2], npts int32 [P] (GPU) -> ctrl float32 [P,n_max-1,4,2]."""
+        import torch
+        P, n_max, _ = path.shape
+        ctrl = torch.empty((P, n_max - 1, 4, 2), dtype=torch.float32, device=path.device)
+        nl = 0 if lines is None else lines.shape[0]
+        self._ck(self._l.sc_bezier_from_path_batch(self._h, _ptr(path), _ptr(npts), P, n_max, start_angle,
+                                                   _ptr(lines) if nl else None, nl, _ptr(ctrl)), "sc_bezier_from_path_batch")
+        return ctrl
+
+    def bezier_eval(self, ctrl, seg, t, order=0):
+        import torch
+        M = t.shape[0]
+        out = torch.empty((M, 2), dtype=torch.float32, device=t.device)
+        self._ck(self._l.sc_bezier_eval_batch(self._h, _ptr(ctrl), _ptr(seg), _ptr(t), M, order, _ptr(out)), "sc_bezier_eval_batch")
+        return out
+
+    def bezier_arclength(self, ctrl, nsub=100):
+        """ctrl float32 [...,4,2] (GPU) -> (cum float32 [S,nsub+1], seg_len float32 [S])."""
+        import torch
+        c = ctrl.reshape(-1, 4, 2)
+        S = c.shape[0]
+        cum = torch.empty((S, nsub + 1), dtype=torch.float32, device=ctrl.device)
+        seg_len = torch.empty(S, dtype=torch.float32, device=ctrl.device)
+        self._ck(self._l.sc_bezier_arclength_batch(self._h, _ptr(c), S, nsub, _ptr(cum), _ptr(seg_len)), "sc_bezier_arclength_batch")
+        return cum, seg_len
 
     # -- host-pointer entry points (numpy)
     def edt_host(self, occ):

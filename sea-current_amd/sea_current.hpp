@@ -12,6 +12,7 @@
 //   planning_space::is_free            :1289-1292         same signature
 //   planning_space::cost               :1315-1326         same signature and FLT_MAX convention
 //   planning_space::fast_marching_trees:1339-1407         same signature; grid EDT + batched A* on the GPU
+//   bezier_spline::from_path / arclength :599-683,:767-896  same signatures, GPU tangents + GL-32 tables
 //   velocity_profile                   :379-386           same members
 //   vel_lim_func                       :1175              same shape
 //   gen_vel_prof<N>                    :1191-1265         same argument order (END before START), GPU TOPP-RA
@@ -20,8 +21,9 @@
 // Differences that are deliberate: obstacle::closed is initialised (the reference leaves it
 // uninitialised, :197); library code never prints or calls std::exit (SC_ASSERT throws in DEBUG);
 // all functions are `inline` (the reference defines non-inline functions in a header).
-// Not mirrored yet ("next"): bezier_spline, arclength/resample, chebfit, FMT* sampling
-// helpers (halton, sample_free, near), JSON/ZMQ I/O.
+// Also mirrored from the "next" rows: bezier_spline::from_path and ::arclength.
+// Not mirrored yet: bezier_curve sampling / resample / chebfit, FMT* sampling helpers (halton,
+// sample_free, near), JSON/ZMQ I/O.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -345,6 +347,62 @@ public:
             out[q] = std::move(wp);
         }
         return out;
+    }
+};
+
+// ---- path smoothing (sea_current.hpp:321-326, 388-431, 599-683, 767-896) ---------------------------
+struct arclength_data {
+    float arclength = 0;
+    std::vector<VectorXf> segments;   // cumulative arclength of each segment at t = k * precision
+    std::vector<VectorXf> positions;  // the parameters t of those table entries
+};
+
+class bezier_spline {
+public:
+    std::vector<std::vector<Vector2f>> ctrl_pts;  // 4 control points per leg
+
+    bezier_spline() = default;
+    int n_segments() const { return (int)ctrl_pts.size(); }
+    int degree() const { return ctrl_pts.empty() ? 0 : (int)ctrl_pts[0].size() - 1; }
+
+    // cubic Bezier spline through a piecewise-linear path; tangents by the Lau09 heuristics, shrunk
+    // against the obstacle edges of `ps` (same signature as :599; the tangents and control points are
+    // computed on the GPU, sc_bezier_from_path_batch)
+    static bezier_spline from_path(const std::vector<Vector2f>& path, const planning_space& ps, float start_angle = NAN,
+                                   gpu_context& ctx = default_context()) {
+        SC_ASSERT(path.size() >= 2, "Not enough points for a path");
+        const int n = (int)path.size();
+        std::vector<float> xy(2 * (size_t)n), lines;
+        for (int i = 0; i < n; ++i) { xy[2 * i] = path[i].x(); xy[2 * i + 1] = path[i].y(); }
+        for (const auto& ob : ps.obstacles)
+            for (const auto& [a, b] : ob.lines) { lines.push_back(a.x()); lines.push_back(a.y()); lines.push_back(b.x()); lines.push_back(b.y()); }
+        const int32_t npts = n;
+        std::vector<float> c(8 * (size_t)(n - 1));
+        ctx.check(sc_bezier_from_path_batch_host(ctx.get(), xy.data(), &npts, 1, n, start_angle, lines.empty() ? nullptr : lines.data(),
+                                                 (int)(lines.size() / 4), c.data()), "sc_bezier_from_path_batch_host");
+        bezier_spline bs;
+        bs.ctrl_pts.resize(n - 1);
+        for (int i = 0; i < n - 1; ++i)
+            for (int k = 0; k < 4; ++k) bs.ctrl_pts[i].push_back(Vector2f(c[8 * i + 2 * k], c[8 * i + 2 * k + 1]));
+        return bs;
+    }
+
+    // 32-point Gauss-Legendre arclength tables, 1/precision sub-intervals per segment (same as :765-896)
+    arclength_data arclength(const float precision = 0.01f, gpu_context& ctx = default_context()) const {
+        arclength_data ad;
+        const int S = n_segments(), nsub = (int)std::lround(1.0f / precision);
+        if (S == 0) return ad;
+        std::vector<float> c(8 * (size_t)S), cum((size_t)S * (nsub + 1)), len(S);
+        for (int i = 0; i < S; ++i)
+            for (int k = 0; k < 4; ++k) { c[8 * i + 2 * k] = ctrl_pts[i][k].x(); c[8 * i + 2 * k + 1] = ctrl_pts[i][k].y(); }
+        ctx.check(sc_bezier_arclength_batch_host(ctx.get(), c.data(), S, nsub, cum.data(), len.data()), "sc_bezier_arclength_batch_host");
+        ad.segments.assign(S, VectorXf::Zero(nsub + 1));
+        ad.positions.assign(S, VectorXf::Zero(nsub + 1));
+        for (int i = 0; i < S; ++i) {
+            for (int k = 0; k <= nsub; ++k) { ad.segments[i](k) = cum[(size_t)i * (nsub + 1) + k]; ad.positions[i](k) = std::min(k * precision, 1.0f); }
+            ad.arclength += len[i];
+        }
+        return ad;
     }
 };
 

@@ -41,6 +41,18 @@ int main() {
     CHECK(batch.size() == 2 && batch[0].has_value() && batch[1].has_value());
     CHECK(batch[0]->size() == path->size());
 
+    // --- smoothing: examples/zmq_test.cpp:61-68 on the recorded request (0,0),(10,0),(10,10) ---
+    {
+        const bounding_rect br2 = {10, -10, 10, -10};
+        planning_space free_space(br2);
+        bezier_spline pad = bezier_spline::from_path({Vector2f(0, 0), Vector2f(10, 0), Vector2f(10, 10)}, free_space);
+        CHECK(pad.n_segments() == 2 && pad.degree() == 3);
+        CHECK(std::fabs(pad.ctrl_pts[0][1].x() - 5.0f) < 1e-5f && std::fabs(pad.ctrl_pts[1][2].y() - 5.0f) < 1e-5f);
+        const arclength_data ad = pad.arclength();
+        CHECK(std::fabs(ad.arclength - 21.38861656f) < 2e-5f);                 // output.json: arclength.arclength
+        CHECK(ad.segments.size() == 2 && ad.segments[0].rows() == 101);
+        CHECK(std::fabs(ad.positions[0](100) - 1.0f) < 1e-6f);
+    }
     // --- velocity profile: examples/zmq_test.cpp:69-88 with the recorded arclength of output.json ---
     const double L = 21.38861656188965;
     auto vel_lim = [&](value_type) {
