@@ -374,7 +374,7 @@ __device__ __noinline__ uint32_t edt_gdist_global(const uint32_t* cb, int W, int
 }
 
 template <int PPL, bool FULL>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, 8)
 edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
     static_assert(PPL == 8 || PPL == 16, "g8 path: 8 or 16 pixels per lane");
     constexpr int WAVES = 8;
@@ -388,6 +388,10 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     const int b = blockIdx.x % nb, g = blockIdx.x / nb;
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
+#ifdef EDT_ABLATE_PHASE1   // timing-only: no look-back / recurrence, constant distances
+    for (int q = threadIdx.x; q < 32 * WP / 4; q += WAVES * 64) smem[q] = 0x03020302u + (cb[(size_t)b * W + (q & (W - 1))] & 1u);
+    if (false)
+#endif
     // ---- phase 1: two adjacent columns per thread -> 32 rows of 2 distance bytes ----
     for (int q = threadIdx.x; q < WP / 2; q += WAVES * 64) {
         uint32_t nw[2];
@@ -436,8 +440,9 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                 nw[c] = ~w[c];
             }
         }
-        // top-down: gu = rows to the nearest obstacle at or above; stored clamped at 255
-        uint32_t GU[32];
+        // top-down: gu = rows to the nearest obstacle at or above, clamped at 255 and kept two rows per
+        // VGPR (bytes: row 2m in [7:0] / [23:16], row 2m+1 in [15:8] / [31:24]) to stay within 64 VGPRs
+        uint32_t GU2[16];
         uint32_t gu = (uint32_t)(up[0] - 1) | ((uint32_t)(up[1] - 1) << 16);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -445,26 +450,40 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             const uint32_t keep = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)nw[1], i, 1),
                                                         (uint32_t)__builtin_amdgcn_sbfe((int)nw[0], i, 1), 0x05040100u);
             gu = pk_add_sat(gu, 0x00010001u) & keep;
-            GU[i] = pk_min(gu, 0x00FF00FFu);
+            const uint32_t guc = pk_min(gu, 0x00FF00FFu);
+            if (i & 1) GU2[i >> 1] |= guc << 8; else GU2[i >> 1] = guc;
         }
         // bottom-up: gd restarts at 0 wherever gu == 0 (an obstacle); values past 255 may be clipped
         // at >= 256 because only min(g, 255) is kept
         uint32_t gd = (uint32_t)(dn[0] - 1) | ((uint32_t)(dn[1] - 1) << 16);
 #pragma unroll
         for (int i = 31; i >= 0; --i) {
-            const uint32_t cap = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, GU[i]) << (us2_t)8);
+            const uint32_t guc = ((i & 1) ? (GU2[i >> 1] >> 8) : GU2[i >> 1]) & 0x00FF00FFu;
+            const uint32_t cap = guc << 8;   // <= 0xFF00 per half
             gd = pk_min(pk_add_sat(gd, 0x00010001u), cap);
-            const uint32_t gg = pk_min(GU[i], gd);
+            const uint32_t gg = pk_min(guc, gd);
             *reinterpret_cast<uint16_t*>(g8 + (size_t)i * WP + 2 * q) = (uint16_t)((gg & 0xFFu) | ((gg >> 8) & 0xFF00u));
         }
     }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* tr = trs + (size_t)wave * TRN;
     const int y0 = b * 32;
     const int nrows = min(32, H - y0);
     const int nvalid = W - PPL * lane;
+    // PPL == 16: a wave's transposition buffer is 1 KiB of its own (lanes 0..31) plus the g8 row it
+    // processes first (row `wave`, lanes 32..63), which nobody else reads and which is dead once the wave
+    // has pulled it into registers.  The kernel then needs 40 KiB of LDS and four workgroups (32 waves) fit.
+    uint32_t* tr = trs + (size_t)wave * TRN;
+    uint32_t* trb = tr;   // buffer half of lanes 32..63
+    if constexpr (PPL == 16) {
+        tr = trs + (size_t)wave * 256;
+        trb = smem + (size_t)wave * (WP / 4) - 256;   // so that trb[8 * lane + r] with lane >= 32 lands in row `wave`
+    }
+#ifdef EDT_ABLATE_ROWS   // timing-only: phase 1 alone (one store keeps it alive)
+    if (threadIdx.x == 0) d2[((size_t)g * H + y0) * W] = g8[lane];
+    if (true) return;
+#endif
     for (int i = wave; i < nrows; i += WAVES) {
         int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
         uint32_t P[HP];
@@ -523,17 +542,29 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
         }
         if (!saturated) {
             // packed transpose: lane writes its HP packed registers, reads back u16 halves so that
-            // each lane then holds 4 consecutive pixels for one 16-byte store
+            // each lane then holds 4 consecutive pixels for one 16-byte store.  PPL == 16: unpadded
+            // 8-dword rows with an XOR swizzle of the register index (bank-conflict free both ways).
 #pragma unroll
-            for (int j = 0; j < HP; ++j) tr[(HP + 1) * lane + j] = P[j];
+            for (int j = 0; j < HP; ++j) {
+                if constexpr (PPL == 16) (lane < 32 ? tr : trb)[8 * lane + (j ^ ((lane >> 2) & 7))] = P[j];
+                else tr[(HP + 1) * lane + j] = P[j];
+            }
             wave_lds_sync();
             const uint16_t* trh = reinterpret_cast<const uint16_t*>(tr);
 #pragma unroll
             for (int k = 0; k < PPL / 4; ++k) {
                 const int x = 4 * (64 * k + lane);
                 const int l2 = x / PPL, j2 = x % PPL;                    // owner lane, pixel index there
-                const int hidx = 2 * ((HP + 1) * l2 + (j2 % HP)) + (j2 >= HP ? 1 : 0);
-                int4 v = make_int4(trh[hidx], trh[hidx + 2], trh[hidx + 4], trh[hidx + 6]);
+                int4 v;
+                if constexpr (PPL == 16) {
+                    const uint16_t* trh = reinterpret_cast<const uint16_t*>(l2 < 32 ? tr : trb);
+                    const int sw = (l2 >> 2) & 7, r0 = j2 % HP, hf = j2 >= HP ? 1 : 0;
+                    v = make_int4(trh[2 * (8 * l2 + ((r0 + 0) ^ sw)) + hf], trh[2 * (8 * l2 + ((r0 + 1) ^ sw)) + hf],
+                                  trh[2 * (8 * l2 + ((r0 + 2) ^ sw)) + hf], trh[2 * (8 * l2 + ((r0 + 3) ^ sw)) + hf]);
+                } else {
+                    const int hidx = 2 * ((HP + 1) * l2 + (j2 % HP)) + (j2 >= HP ? 1 : 0);
+                    v = make_int4(trh[hidx], trh[hidx + 2], trh[hidx + 4], trh[hidx + 6]);
+                }
                 if (FULL || x + 3 < W) {
                     if (FULL || (((uintptr_t)(out + x)) & 15) == 0) EDT_STORE4(out + x, v);
                     else { out[x] = v.x; out[x + 1] = v.y; out[x + 2] = v.z; out[x + 3] = v.w; }
@@ -587,7 +618,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
 template <int PPL, bool FULL>
 static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     constexpr int WP = 64 * PPL;
-    const size_t lds = (size_t)32 * WP + (size_t)8 * 64 * (PPL / 2 + 1) * sizeof(uint32_t);
+    const size_t lds = PPL == 16 ? (size_t)32 * WP + 8 * 1024 : (size_t)32 * WP + (size_t)8 * 64 * (PPL / 2 + 1) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_g8_kernel<PPL, FULL>),
