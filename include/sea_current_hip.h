@@ -60,7 +60,8 @@ typedef enum {
     SC_K_TOPPRA_SAMPLE = 5,
     SC_K_BEZIER = 6,      /* tangents + control points, curve evaluation */
     SC_K_ARCLENGTH = 7,   /* GL-32 arclength tables */
-    SC_K_COUNT = 8
+    SC_K_RESAMPLE = 8,    /* resample: nudge + split, Chebyshev fit + evaluation */
+    SC_K_COUNT = 9
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -185,12 +186,30 @@ int sc_bezier_from_path_batch_host(sc_ctx* ctx, const float* path, const int32_t
  * into ctrl viewed as [S][4][2]) at parameter t[i]; out float [M][2].  Takes over
  * bezier_spline::bezier_curve (:700-763) and ::hodograph (:1041-1053). */
 int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_t* seg, const float* t, int M, int order, float* out);
+/* host-pointer form; S = number of segments in ctrl */
+int sc_bezier_eval_batch_host(sc_ctx* ctx, const float* ctrl, int S, const int32_t* seg, const float* t, int M, int order, float* out);
 /* bezier_spline::arclength (:767-896): 32-point Gauss-Legendre on nsub (= 1/precision)
  * sub-intervals of every segment.  cum float [S][nsub+1] cumulative length at
  * t = k/nsub, seg_len float [S] (the reference's arclength_data: segments, and
  * arclength = sum of seg_len over a path). */
 int sc_bezier_arclength_batch(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len);
 int sc_bezier_arclength_batch_host(sc_ctx* ctx, const float* ctrl, int S, int nsub, float* cum, float* seg_len);
+/* bezier_spline::resample (:898-1005) with chebfit / chebeval (:1109-1170) and ::curvature (:1017-1039): map the
+ * arclength positions of a velocity profile back onto the curve.  B splines; spline b owns segments
+ * seg_off[b] .. seg_off[b+1]-1 (S = seg_off[B] in total) of ctrl [S][4][2] and of the tables cum [S][nsub+1]
+ * (sc_bezier_arclength_batch), has total length arclength[b], and samples prof_off[b] .. prof_off[b+1]-1 of
+ * profile_pos (M = prof_off[B] in total).  nudge != 0 first repairs profile_pos IN PLACE the way the reference does
+ * (:902-913: ends pinned to 0 / arclength, non-monotone samples averaged, clamped).  Per sample: pts float [M][2],
+ * tpar float [M] (curve parameter), seg int32 [M] (segment within the spline), curvature float [M] -- each may be
+ * NULL.  status int32 [B]: 0, or 1 when a segment received no sample (the reference indexes out of range there; the
+ * spline's outputs are then unspecified).  nsub <= SC_RESAMPLE_MAX_NSUB. */
+#define SC_RESAMPLE_MAX_NSUB 512
+int sc_bezier_resample_batch(sc_ctx* ctx, const float* ctrl, const float* cum, const float* arclength, const int32_t* seg_off,
+                             int B, int S, int nsub, float* profile_pos, const int32_t* prof_off, int nudge, float* pts,
+                             float* tpar, int32_t* seg, float* curvature, int32_t* status);
+int sc_bezier_resample_batch_host(sc_ctx* ctx, const float* ctrl, const float* cum, const float* arclength, const int32_t* seg_off,
+                                  int B, int S, int nsub, float* profile_pos, const int32_t* prof_off, int nudge, float* pts,
+                                  float* tpar, int32_t* seg, float* curvature, int32_t* status);
 
 #ifdef __cplusplus
 }

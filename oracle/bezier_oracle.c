@@ -132,3 +132,114 @@ double sco_bezier_arclength(const float* ctrl, int nseg, int nsub, double* cum) 
     }
     return total;
 }
+
+/* ---- resample (:898-1005) with chebfit / chebeval (:1109-1170) and curvature (:1017-1039) ----------------
+ * PINNED by examples/output.json: pos_x / pos_y (1.1e-5 absolute on coordinates up to 11) and ang_vel = vel * curvature
+ * (9e-8) of the recorded run (tests/test_oracle_bezier.py).  The reference fits in float32 (Eigen HouseholderQR);
+ * this restatement runs the same Householder least-squares fit in fp64 on the float32 tables. */
+
+/* least-squares Chebyshev fit of y(x), columns T_0..T_{deg-1} of the normalised abscissa; coef [deg] */
+static void chebfit(const float* x, const double* y, int m, int deg, double* coef, double* xmin_o, double* xmax_o) {
+    double xmin = x[0], xmax = x[0];
+    for (int r = 1; r < m; ++r) { if (x[r] < xmin) xmin = x[r]; if (x[r] > xmax) xmax = x[r]; }
+    const int nc = deg + 1;                       /* [T | y] */
+    double* A = (double*)malloc(sizeof(double) * m * nc);
+    for (int r = 0; r < m; ++r) {
+        const double xn = (2 * (double)x[r] - (xmax + xmin)) / (xmax - xmin);
+        double* a = A + (size_t)r * nc;
+        a[0] = 1;
+        if (deg > 1) a[1] = xn;
+        for (int j = 2; j < deg; ++j) a[j] = 2 * xn * a[j - 1] - a[j - 2];
+        a[deg] = y[r];
+    }
+    for (int k = 0; k < deg && k < m; ++k) {      /* Householder reflections, column by column */
+        double nrm = 0;
+        for (int r = k; r < m; ++r) nrm += A[(size_t)r * nc + k] * A[(size_t)r * nc + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0) continue;
+        const double akk = A[(size_t)k * nc + k], alpha = akk > 0 ? -nrm : nrm;
+        const double vk = akk - alpha, vtv = nrm * nrm - akk * akk + vk * vk;    /* v = a_k - alpha e_k */
+        for (int j = k + 1; j < nc; ++j) {
+            double dot = vk * A[(size_t)k * nc + j];
+            for (int r = k + 1; r < m; ++r) dot += A[(size_t)r * nc + k] * A[(size_t)r * nc + j];
+            const double f = 2 * dot / vtv;
+            A[(size_t)k * nc + j] -= f * vk;
+            for (int r = k + 1; r < m; ++r) A[(size_t)r * nc + j] -= f * A[(size_t)r * nc + k];
+        }
+        A[(size_t)k * nc + k] = alpha;
+    }
+    for (int k = deg - 1; k >= 0; --k) {          /* R c = (Q^T y)[0:deg] */
+        double s = A[(size_t)k * nc + deg];
+        for (int j = k + 1; j < deg; ++j) s -= A[(size_t)k * nc + j] * coef[j];
+        coef[k] = s / A[(size_t)k * nc + k];
+    }
+    free(A);
+    *xmin_o = xmin; *xmax_o = xmax;
+}
+
+static double chebeval(double x, const double* coef, int deg, double xmin, double xmax) {
+    const double xn = (2 * x - (xmax + xmin)) / (xmax - xmin);
+    double t0 = 1, t1 = xn, y = coef[0];
+    if (deg > 1) y += coef[1] * t1;
+    for (int j = 2; j < deg; ++j) { const double t2 = 2 * xn * t1 - t0; y += coef[j] * t2; t0 = t1; t1 = t2; }
+    return y;
+}
+
+/* One spline of nseg cubic segments with arclength tables cum [nseg][nsub+1] (float, as arclength_data holds them) and
+ * total `arclength`; profile_pos [n] are arclength positions over time (modified in place when nudge != 0, as the
+ * reference's by-reference argument is).  Outputs (each may be NULL): pts [n][2], tpar [n] the curve parameter,
+ * seg [n] the segment, curv [n] the signed curvature.  Returns 0, or 1 when some segment received no sample (the
+ * reference indexes out of range there); outputs are then unspecified. */
+int sco_bezier_resample(const float* ctrl, int nseg, int nsub, const float* cum, float arclength, float* pp, int n, int nudge,
+                        float* pts, float* tpar, int32_t* seg, float* curv) {
+    if (n <= 0 || nseg <= 0) return 1;
+    int status = 0;
+    if (nudge) {                                  /* :902-913 */
+        pp[0] = 0; pp[n - 1] = arclength;
+        for (int i = 1; i < n - 1; ++i) {
+            if (pp[i] < pp[i - 1] || pp[i] > pp[i + 1]) pp[i] = (pp[i - 1] + pp[i + 1]) / 2;
+            if (pp[i] < 0) pp[i] = 0;
+            if (pp[i] > arclength) pp[i] = arclength;
+        }
+    }
+    const int m = nsub + 1, deg = m < 10 ? m : 10;    /* :951 */
+    double* y = (double*)malloc(sizeof(double) * m);
+    const float prec = 1.0f / (float)nsub;
+    for (int k = 0; k < m; ++k) { const float v = (float)k * prec; y[k] = v < 1.0f ? v : 1.0f; }   /* arclength_data::positions */
+    int j = 0;
+    float offset = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const float* tab = cum + (size_t)i * m;
+        const float last = tab[m - 1];
+        const int start = j;
+        for (; j < n && (pp[j] - offset <= last); ++j) {}
+        if (i + 1 == nseg && i == 0) j = n;
+        else if (i + 1 == nseg) j = n - 1;
+        j -= 1;
+        if (j < start) { status = 1; j = start; }
+        offset = pp[j];
+        double coef[10], xmin, xmax;
+        chebfit(tab, y, m, deg, coef, &xmin, &xmax);
+        for (int k = start; k <= j; ++k) {
+            const int o = k + i;                   /* blocks overlap by one sample; the surplus is cut off the end (:983-993) */
+            if (o >= n) break;
+            const float xb = pp[k] - pp[start];
+            float t = (float)chebeval((double)xb, coef, deg, xmin, xmax);
+            if (t < 0) t = 0;
+            if (t > 1) t = 1;
+            double p[2], d1[2], d2[2];
+            const double td = t;
+            sco_bezier_eval(ctrl, &i, &td, 1, 0, p);
+            if (pts) { pts[2 * o] = (float)p[0]; pts[2 * o + 1] = (float)p[1]; }
+            if (tpar) tpar[o] = t;
+            if (seg) seg[o] = i;
+            if (curv) {
+                sco_bezier_eval(ctrl, &i, &td, 1, 1, d1);
+                sco_bezier_eval(ctrl, &i, &td, 1, 2, d2);
+                curv[o] = (float)((d1[0] * d2[1] - d1[1] * d2[0]) / pow(d1[0] * d1[0] + d1[1] * d1[1], 1.5));
+            }
+        }
+    }
+    free(y);
+    return status;
+}

@@ -152,3 +152,21 @@ def bezier_arclength(ctrl, nsub=100):
     cum = np.zeros((nseg, nsub + 1))
     total = lib().sco_bezier_arclength(_p(ctrl, C.c_float), C.c_int(nseg), C.c_int(nsub), _p(cum, C.c_double))
     return total, cum
+
+
+def bezier_resample(ctrl, cum, arclength, profile_pos, nudge=True):
+    """resample (sea_current.hpp:898-1005) -> dict(status, pos (nudged), pts [n,2], t [n], seg [n], curvature [n])."""
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    cum = np.ascontiguousarray(cum, dtype=np.float32)
+    nseg, m = cum.shape
+    pp = np.array(profile_pos, dtype=np.float32)
+    n = pp.shape[0]
+    pts = np.zeros((n, 2), np.float32)
+    tpar = np.zeros(n, np.float32)
+    seg = np.zeros(n, np.int32)
+    curv = np.zeros(n, np.float32)
+    f = lib().sco_bezier_resample
+    f.restype = C.c_int
+    st = f(_p(ctrl, C.c_float), C.c_int(nseg), C.c_int(m - 1), _p(cum, C.c_float), C.c_float(float(arclength)), _p(pp, C.c_float),
+           C.c_int(n), C.c_int(1 if nudge else 0), _p(pts, C.c_float), _p(tpar, C.c_float), _p(seg, C.c_int32), _p(curv, C.c_float))
+    return dict(status=st, pos=pp, pts=pts, t=tpar, seg=seg, curvature=curv)

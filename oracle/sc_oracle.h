@@ -105,6 +105,11 @@ void sco_bezier_from_path(const float* path, int n, float start_angle, const flo
 void sco_bezier_eval(const float* ctrl, const int* seg, const double* t, int m, int order, double* out);
 /* arclength (:767-896): GL-32 on nsub sub-intervals per segment; cum [nseg][nsub+1]; returns the total */
 double sco_bezier_arclength(const float* ctrl, int nseg, int nsub, double* cum);
+/* resample (:898-1005; chebfit/chebeval :1109-1170; curvature :1017-1039): map arclength positions over time
+ * (profile_pos [n], nudged in place when nudge != 0) to curve points.  cum: float tables [nseg][nsub+1].
+ * pts [n][2], tpar [n], seg [n], curv [n] (each may be NULL).  Returns 0, or 1 if a segment got no sample. */
+int sco_bezier_resample(const float* ctrl, int nseg, int nsub, const float* cum, float arclength, float* profile_pos, int n,
+                        int nudge, float* pts, float* tpar, int32_t* seg, float* curv);
 
 #ifdef __cplusplus
 }

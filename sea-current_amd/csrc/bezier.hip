@@ -154,6 +154,175 @@ bezier_arclength_kernel(const float* __restrict__ ctrl, int S, int nsub, const d
     if (lane == 63) seg_len[s] = (float)incl;
 }
 
+// ---- resample (sea_current.hpp:898-1005, chebfit / chebeval :1109-1170, curvature :1017-1039) ------------------
+// Kernel 1, one wavefront per spline: the reference's sequential "nudge" of the profile positions (chunks of 64
+// samples are checked in parallel; a chunk with a sample to fix is replayed in order by lane 0, which keeps the
+// sequential semantics exactly) and the split of the samples over the segments (first sample past the end of a
+// segment's table, found by ballot).  seginfo [S] = (first sample, last sample, spline, segment within spline).
+__global__ void __launch_bounds__(64)
+resample_prepare_kernel(const float* __restrict__ cum, const int32_t* __restrict__ seg_off, int nsub, const float* __restrict__ arclen,
+                        float* pp_all, const int32_t* __restrict__ prof_off, int nudge, int4* __restrict__ seginfo,
+                        int32_t* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int s0 = seg_off[b], nseg = seg_off[b + 1] - s0;
+    float* pp = pp_all + prof_off[b];
+    const int n = prof_off[b + 1] - prof_off[b];
+    if (n <= 0 || nseg <= 0) {
+        if (lane == 0) status[b] = 1;
+        for (int i = lane; i < nseg; i += 64) seginfo[s0 + i] = make_int4(0, -1, b, i);
+        return;
+    }
+    const float AL = arclen[b];
+    if (nudge) {
+        if (lane == 0) { pp[0] = 0.f; pp[n - 1] = AL; }
+        __threadfence();
+        __syncthreads();
+        for (int base = 1; base < n - 1; base += 64) {
+            const int i = base + lane;
+            bool fix = false;
+            if (i < n - 1) {
+                const float a = pp[i - 1], v = pp[i], c = pp[i + 1];
+                fix = v < a || v > c || v < 0.f || v > AL;
+            }
+            if (__ballot(fix) == 0ull) continue;
+            if (lane == 0) {
+                const int e = min(base + 64, n - 1);
+                for (int k = base; k < e; ++k) {
+                    float v = pp[k];
+                    if (v < pp[k - 1] || v > pp[k + 1]) v = (pp[k - 1] + pp[k + 1]) / 2;
+                    if (v < 0.f) v = 0.f;
+                    if (v > AL) v = AL;
+                    pp[k] = v;
+                }
+            }
+            __threadfence();
+            __syncthreads();
+        }
+    }
+    const int m = nsub + 1;
+    int j = 0, st = 0;
+    float offset = 0.f;
+    for (int i = 0; i < nseg; ++i) {
+        const float last = cum[(size_t)(s0 + i) * m + m - 1];
+        const int start = j;
+        while (j < n) {
+            const int k = j + lane;
+            const bool past = k >= n || !(pp[k] - offset <= last);
+            const unsigned long long bal = __ballot(past);
+            if (bal) { j += __ffsll((long long)bal) - 1; break; }
+            j += 64;
+        }
+        if (j > n) j = n;
+        if (i + 1 == nseg && i == 0) j = n;
+        else if (i + 1 == nseg) j = n - 1;
+        j -= 1;
+        if (j < start) { st = 1; j = start; }
+        offset = pp[j];
+        if (lane == 0) seginfo[s0 + i] = make_int4(start, j, b, i);
+    }
+    if (lane == 0) status[b] = st;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Kernel 2, one workgroup per segment: wave 0 fits the Chebyshev polynomial arclength -> parameter by Householder
+// least squares in fp64 ([T | y] of (nsub+1) x (deg+1) in LDS, rows over lanes), then all threads evaluate the
+// segment's block of samples: parameter, point, curvature.
+__global__ void __launch_bounds__(256)
+resample_eval_kernel(const float* __restrict__ ctrl, const float* __restrict__ cum, int nsub, const float* __restrict__ pp_all,
+                     const int32_t* __restrict__ prof_off, const int4* __restrict__ seginfo, float* __restrict__ pts,
+                     float* __restrict__ tpar, int32_t* __restrict__ seg, float* __restrict__ curv) {
+    extern __shared__ double A[];                 // [m][nc]
+    __shared__ double coef[10];
+    __shared__ double xr[2];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int4 info = seginfo[s];
+    const int m = nsub + 1, deg = m < 10 ? m : 10, nc = deg + 1;
+    const float* tab = cum + (size_t)s * m;
+    if (tid < 64) {
+        const int lane = tid;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int r = lane; r < m; r += 64) { mn = fminf(mn, tab[r]); mx = fmaxf(mx, tab[r]); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+        const double xmin = mn, xmax = mx;
+        const float prec = 1.0f / (float)nsub;
+        for (int r = lane; r < m; r += 64) {
+            const double xn = (2 * (double)tab[r] - (xmax + xmin)) / (xmax - xmin);
+            double* a = A + (size_t)r * nc;
+            a[0] = 1;
+            if (deg > 1) a[1] = xn;
+            for (int j = 2; j < deg; ++j) a[j] = 2 * xn * a[j - 1] - a[j - 2];
+            const float v = (float)r * prec;
+            a[deg] = v < 1.0f ? v : 1.0f;
+        }
+        wave_lds_sync();
+        for (int k = 0; k < deg && k < m; ++k) {
+            double part = 0;
+            for (int r = k + lane; r < m; r += 64) part += A[(size_t)r * nc + k] * A[(size_t)r * nc + k];
+            const double n2 = wave_sum(part), nrm = sqrt(n2);
+            if (nrm == 0) continue;
+            const double akk = A[(size_t)k * nc + k], alpha = akk > 0 ? -nrm : nrm;
+            const double vk = akk - alpha, vtv = nrm * nrm - akk * akk + vk * vk;
+            wave_lds_sync();                      // everyone has read a_kk before column k's head is touched
+            for (int j = k + 1; j < nc; ++j) {
+                double d = 0;
+                for (int r = k + 1 + lane; r < m; r += 64) d += A[(size_t)r * nc + k] * A[(size_t)r * nc + j];
+                d = wave_sum(d) + vk * A[(size_t)k * nc + j];
+                const double f = 2 * d / vtv;
+                wave_lds_sync();
+                for (int r = k + 1 + lane; r < m; r += 64) A[(size_t)r * nc + j] -= f * A[(size_t)r * nc + k];
+                if (lane == 0) A[(size_t)k * nc + j] -= f * vk;
+                wave_lds_sync();
+            }
+            if (lane == 0) A[(size_t)k * nc + k] = alpha;
+            wave_lds_sync();
+        }
+        if (lane == 0) {
+            for (int k = deg - 1; k >= 0; --k) {
+                double v = A[(size_t)k * nc + deg];
+                for (int j = k + 1; j < deg; ++j) v -= A[(size_t)k * nc + j] * coef[j];
+                coef[k] = v / A[(size_t)k * nc + k];
+            }
+            xr[0] = xmin; xr[1] = xmax;
+        }
+    }
+    __syncthreads();
+    const int start = info.x, end = info.y, b = info.z, il = info.w;
+    const int p0 = prof_off[b], n = prof_off[b + 1] - p0;
+    const float* pp = pp_all + p0;
+    const double xmin = xr[0], xmax = xr[1];
+    const float* c = ctrl + (size_t)s * 8;
+    for (int k = start + tid; k <= end; k += 256) {
+        const int o = k + il;
+        if (o >= n) break;
+        const float xb = pp[k] - pp[start];
+        const double xn = (2 * (double)xb - (xmax + xmin)) / (xmax - xmin);
+        double t0 = 1, t1 = xn, y = coef[0];
+        if (deg > 1) y += coef[1] * t1;
+        for (int j = 2; j < deg; ++j) { const double t2 = 2 * xn * t1 - t0; y += coef[j] * t2; t0 = t1; t1 = t2; }
+        float t = (float)y;
+        if (t < 0.f) t = 0.f;
+        if (t > 1.f) t = 1.f;
+        const size_t og = (size_t)p0 + o;
+        double px, py;
+        bez_eval(c, (double)t, 0, px, py);
+        if (pts) { pts[2 * og] = (float)px; pts[2 * og + 1] = (float)py; }
+        if (tpar) tpar[og] = t;
+        if (seg) seg[og] = il;
+        if (curv) {
+            double ax, ay, bx, by;
+            bez_eval(c, (double)t, 1, ax, ay);
+            bez_eval(c, (double)t, 2, bx, by);
+            curv[og] = (float)((ax * by - ay * bx) / pow(ax * ax + ay * ay, 1.5));
+        }
+    }
+}
+
 static void gl32_host(double* x, double* w) {
     const int N = 32;
     for (int i = 0; i < N; ++i) {
@@ -210,6 +379,27 @@ extern "C" int sc_bezier_arclength_batch(sc_ctx* ctx, const float* ctrl, int S, 
     int tk = sc_time_begin(ctx, SC_K_ARCLENGTH);
     hipLaunchKernelGGL(bezier_arclength_kernel, dim3(S), dim3(64), (size_t)nsub * sizeof(double), ctx->stream, ctrl, S, nsub,
                        (const double*)ctx->bez_gl.p, cum, seg_len);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_bezier_resample_batch(sc_ctx* ctx, const float* ctrl, const float* cum, const float* arclength, const int32_t* seg_off,
+                                        int B, int S, int nsub, float* profile_pos, const int32_t* prof_off, int nudge, float* pts,
+                                        float* tpar, int32_t* seg, float* curvature, int32_t* status) {
+    if (!ctx || !ctrl || !cum || !arclength || !seg_off || !profile_pos || !prof_off || !status || B <= 0 || S <= 0 || nsub <= 0 ||
+        nsub > SC_RESAMPLE_MAX_NSUB)
+        return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int r = sc_scratch_reserve(ctx, &ctx->bez_seginfo, (size_t)S * sizeof(int4));
+    if (r != SC_OK) return r;
+    int4* seginfo = (int4*)ctx->bez_seginfo.p;
+    const int m = nsub + 1, nc = (m < 10 ? m : 10) + 1;
+    int tk = sc_time_begin(ctx, SC_K_RESAMPLE);
+    hipLaunchKernelGGL(resample_prepare_kernel, dim3(B), dim3(64), 0, ctx->stream, cum, seg_off, nsub, arclength, profile_pos, prof_off,
+                       nudge, seginfo, status);
+    hipLaunchKernelGGL(resample_eval_kernel, dim3(S), dim3(256), (size_t)m * nc * sizeof(double), ctx->stream, ctrl, cum, nsub,
+                       (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

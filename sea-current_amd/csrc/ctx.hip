@@ -45,7 +45,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
-    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl);
+    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -297,5 +297,60 @@ extern "C" int sc_bezier_arclength_batch_host(sc_ctx* ctx, const float* ctrl, in
     if (r != SC_OK) return r;
     SC_HIP(ctx, hipMemcpyAsync(cum, b + cb, ub, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(seg_len, b + cb + ub, sb, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_bezier_resample_batch_host(sc_ctx* ctx, const float* ctrl, const float* cum, const float* arclength,
+                                             const int32_t* seg_off, int B, int S, int nsub, float* profile_pos, const int32_t* prof_off,
+                                             int nudge, float* pts, float* tpar, int32_t* seg, float* curvature, int32_t* status) {
+    if (!ctx || !ctrl || !cum || !arclength || !seg_off || !profile_pos || !prof_off || !status || B <= 0 || S <= 0 || nsub <= 0)
+        return SC_ERR_INVALID;
+    if (seg_off[B] != S || seg_off[0] != 0 || prof_off[0] != 0 || prof_off[B] < 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t M = (size_t)prof_off[B];
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ctrl = 0, o_cum = o_ctrl + al((size_t)S * 32), o_al = o_cum + al((size_t)S * (nsub + 1) * 4), o_so = o_al + al((size_t)B * 4),
+                 o_po = o_so + al((size_t)(B + 1) * 4), o_pp = o_po + al((size_t)(B + 1) * 4), o_pts = o_pp + al(M * 4), o_t = o_pts + al(M * 8),
+                 o_sg = o_t + al(M * 4), o_cv = o_sg + al(M * 4), o_st = o_cv + al(M * 4), total = o_st + al((size_t)B * 4);
+    STAGE(4, total);
+    char* b = (char*)ctx->staging[4].p;
+    SC_HIP(ctx, hipMemcpyAsync(b + o_ctrl, ctrl, (size_t)S * 32, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_cum, cum, (size_t)S * (nsub + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_al, arclength, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_so, seg_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_po, prof_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (M) SC_HIP(ctx, hipMemcpyAsync(b + o_pp, profile_pos, M * 4, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_resample_batch(ctx, (const float*)(b + o_ctrl), (const float*)(b + o_cum), (const float*)(b + o_al),
+                                     (const int32_t*)(b + o_so), B, S, nsub, (float*)(b + o_pp), (const int32_t*)(b + o_po), nudge,
+                                     pts ? (float*)(b + o_pts) : nullptr, tpar ? (float*)(b + o_t) : nullptr,
+                                     seg ? (int32_t*)(b + o_sg) : nullptr, curvature ? (float*)(b + o_cv) : nullptr, (int32_t*)(b + o_st));
+    if (r != SC_OK) return r;
+    if (M) {
+        SC_HIP(ctx, hipMemcpyAsync(profile_pos, b + o_pp, M * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (pts) SC_HIP(ctx, hipMemcpyAsync(pts, b + o_pts, M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (tpar) SC_HIP(ctx, hipMemcpyAsync(tpar, b + o_t, M * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (seg) SC_HIP(ctx, hipMemcpyAsync(seg, b + o_sg, M * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (curvature) SC_HIP(ctx, hipMemcpyAsync(curvature, b + o_cv, M * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SC_HIP(ctx, hipMemcpyAsync(status, b + o_st, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_bezier_eval_batch_host(sc_ctx* ctx, const float* ctrl, int S, const int32_t* seg, const float* t, int M, int order,
+                                         float* out) {
+    if (!ctx || !ctrl || !seg || !t || !out || S <= 0 || M <= 0) return SC_ERR_INVALID;
+    for (int i = 0; i < M; ++i)
+        if (seg[i] < 0 || seg[i] >= S) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cb = ((size_t)S * 32 + 255) & ~(size_t)255, mb = ((size_t)M * 4 + 255) & ~(size_t)255;
+    STAGE(5, cb + 2 * mb + (size_t)M * 8);
+    char* b = (char*)ctx->staging[5].p;
+    SC_HIP(ctx, hipMemcpyAsync(b, ctrl, (size_t)S * 32, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + cb, seg, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + cb + mb, t, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_eval_batch(ctx, (const float*)b, (const int32_t*)(b + cb), (const float*)(b + cb + mb), M, order,
+                                 (float*)(b + cb + 2 * mb));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(out, b + cb + 2 * mb, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
     return sc_ctx_synchronize(ctx);
 }

@@ -95,12 +95,6 @@ edt_colbits_generic_kernel(const uint8_t* __restrict__ occ, int W, int H, int nb
     colbits[((size_t)g * nb + b) * W + x] = w;
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave execute in issue order; only the compiler must not reorder them.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // d2 is written once and not read again by this library: non-temporal stores keep the 256 MiB of output
 // from lingering as dirty lines whose write-back would otherwise slow whatever runs next (measured:
 // the following colbits launch drops from ~25 us to ~10 us, the read floor for 64 MiB).

@@ -34,6 +34,7 @@ struct sc_ctx {
     sc_scratch qstats;      // A*: int32 expanded[Q] + flags
     sc_scratch bez_tang;    // Bezier: double [P][n_max][2] tangents
     sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
+    sc_scratch bez_seginfo; // resample: int4 [S] (first sample, last sample, spline, segment in spline)
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
@@ -64,3 +65,11 @@ int sc_time_chain(sc_ctx* ctx, int token, int kid);
 // kernels' host launchers (defined in the respective .hip files)
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
 int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, uint8_t* moves);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in issue order; only the compiler must not reorder them.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#endif

@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH = range(8)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE = range(9)
 
 _lib = None
 
@@ -65,8 +65,11 @@ _SIGNATURES = {
     "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_eval_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sc_bezier_eval_batch_host": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "sc_bezier_arclength_batch_host": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "sc_bezier_arclength_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sc_bezier_resample_batch": (_i, [_vp] * 5 + [_i, _i, _i, _vp, _vp, _i] + [_vp] * 5),
+    "sc_bezier_resample_batch_host": (_i, [_vp] * 5 + [_i, _i, _i, _vp, _vp, _i] + [_vp] * 5),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -271,6 +274,24 @@ class Context:
         seg_len = torch.empty(S, dtype=torch.float32, device=ctrl.device)
         self._ck(self._l.sc_bezier_arclength_batch(self._h, _ptr(c), S, nsub, _ptr(cum), _ptr(seg_len)), "sc_bezier_arclength_batch")
         return cum, seg_len
+
+    def bezier_resample(self, ctrl, cum, arclength, seg_off, profile_pos, prof_off, nudge=True, want_curvature=True):
+        """B splines (GPU tensors): ctrl float32 [S,4,2], cum float32 [S,nsub+1], arclength float32 [B], seg_off int32 [B+1],
+        profile_pos float32 [M] (nudged IN PLACE when `nudge`), prof_off int32 [B+1] -> dict(pts [M,2], t [M], seg [M],
+        curvature [M], status [B])."""
+        import torch
+        S, m = cum.shape
+        B = arclength.shape[0]
+        M = profile_pos.shape[0]
+        dev = profile_pos.device
+        out = dict(pts=torch.zeros((M, 2), dtype=torch.float32, device=dev), t=torch.zeros(M, dtype=torch.float32, device=dev),
+                   seg=torch.zeros(M, dtype=torch.int32, device=dev), status=torch.zeros(B, dtype=torch.int32, device=dev),
+                   curvature=torch.zeros(M, dtype=torch.float32, device=dev) if want_curvature else None)
+        self._ck(self._l.sc_bezier_resample_batch(self._h, _ptr(ctrl), _ptr(cum), _ptr(arclength), _ptr(seg_off), B, S, m - 1,
+                                                  _ptr(profile_pos), _ptr(prof_off), 1 if nudge else 0, _ptr(out["pts"]), _ptr(out["t"]),
+                                                  _ptr(out["seg"]), _ptr(out["curvature"]) if want_curvature else None,
+                                                  _ptr(out["status"])), "sc_bezier_resample_batch")
+        return out
 
     # -- host-pointer entry points (numpy)
     def edt_host(self, occ):

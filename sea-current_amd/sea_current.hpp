@@ -13,6 +13,8 @@
 //   planning_space::cost               :1315-1326         same signature and FLT_MAX convention
 //   planning_space::fast_marching_trees:1339-1407         same signature; grid EDT + batched A* on the GPU
 //   bezier_spline::from_path / arclength :599-683,:767-896  same signatures, GPU tangents + GL-32 tables
+//   bezier_spline::resample            :898-1005          same signature; nudge, split, Chebyshev fit and evaluation on the GPU
+//   bezier_spline::curvature / angular_velocity :1017-1067  same signatures
 //   velocity_profile                   :379-386           same members
 //   vel_lim_func                       :1175              same shape
 //   gen_vel_prof<N>                    :1191-1265         same argument order (END before START), GPU TOPP-RA
@@ -21,9 +23,11 @@
 // Differences that are deliberate: obstacle::closed is initialised (the reference leaves it
 // uninitialised, :197); library code never prints or calls std::exit (SC_ASSERT throws in DEBUG);
 // all functions are `inline` (the reference defines non-inline functions in a header).
-// Also mirrored from the "next" rows: bezier_spline::from_path and ::arclength.
-// Not mirrored yet: bezier_curve sampling / resample / chebfit, FMT* sampling helpers (halton,
-// sample_free, near), JSON/ZMQ I/O.
+// Also mirrored from the "next" rows: bezier_spline::from_path, ::arclength, ::resample,
+// ::curvature, ::angular_velocity -- with these the reference's whole example pipeline (examples/zmq_test.cpp:66-93)
+// runs through this header.  bezier_spline::pts is a std::vector<Vector2f> (the reference: Matrix<float,Dynamic,2>).
+// Not mirrored: the 10001-point display sampling of from_path, FMT* sampling helpers (halton, sample_free, near),
+// JSON/ZMQ I/O.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -357,12 +361,17 @@ struct arclength_data {
     std::vector<VectorXf> positions;  // the parameters t of those table entries
 };
 
+struct velocity_profile;
+
 class bezier_spline {
 public:
     std::vector<std::vector<Vector2f>> ctrl_pts;  // 4 control points per leg
+    std::vector<Vector2f> pts;                    // sampled points (filled by resample), in sample order
+    std::vector<VectorXf> positions;              // per segment: the curve parameters of its samples (as :392)
 
     bezier_spline() = default;
     int n_segments() const { return (int)ctrl_pts.size(); }
+    int n_pts() const { return (int)pts.size(); }
     int degree() const { return ctrl_pts.empty() ? 0 : (int)ctrl_pts[0].size() - 1; }
 
     // cubic Bezier spline through a piecewise-linear path; tangents by the Lau09 heuristics, shrunk
@@ -404,6 +413,68 @@ public:
         }
         return ad;
     }
+
+    // Map the arclength positions of a velocity profile back onto the curve (same signature as :898; profile_pos is
+    // repaired in place when nudge_positions is set, as the reference's by-reference argument is).  Returns the spline
+    // with one point per profile sample; throws if a segment receives no sample (the reference indexes out of range).
+    bezier_spline resample(VectorXf& profile_pos, arclength_data ad, bool nudge_positions = false,
+                           gpu_context& ctx = default_context()) const {
+        SC_ASSERT(profile_pos.rows() > 0, "The vector of positions to be sampled must not be empty");
+        const int S = n_segments(), n = (int)profile_pos.rows();
+        SC_ASSERT((int)ad.segments.size() == S && S > 0, "arclength_data does not belong to this spline");
+        const int nsub = (int)ad.segments[0].rows() - 1;
+        std::vector<float> c(8 * (size_t)S), cum((size_t)S * (nsub + 1)), pp(n), out_pts(2 * (size_t)n), tp(n), cv(n);
+        std::vector<int32_t> sg(n);
+        for (int i = 0; i < S; ++i) {
+            for (int k = 0; k < 4; ++k) { c[8 * i + 2 * k] = ctrl_pts[i][k].x(); c[8 * i + 2 * k + 1] = ctrl_pts[i][k].y(); }
+            for (int k = 0; k <= nsub; ++k) cum[(size_t)i * (nsub + 1) + k] = ad.segments[i](k);
+        }
+        for (int i = 0; i < n; ++i) pp[i] = profile_pos(i);
+        const int32_t seg_off[2] = {0, S}, prof_off[2] = {0, n};
+        int32_t status = 0;
+        ctx.check(sc_bezier_resample_batch_host(ctx.get(), c.data(), cum.data(), &ad.arclength, seg_off, 1, S, nsub, pp.data(), prof_off,
+                                                nudge_positions ? 1 : 0, out_pts.data(), tp.data(), sg.data(), cv.data(), &status),
+                  "sc_bezier_resample_batch_host");
+        if (status != 0) throw std::runtime_error("bezier_spline::resample: a segment of the spline received no profile sample");
+        for (int i = 0; i < n; ++i) profile_pos(i) = pp[i];
+        bezier_spline re;
+        re.ctrl_pts = ctrl_pts;
+        re.pts.resize(n);
+        std::vector<int> cnt(S, 0);
+        for (int i = 0; i < n; ++i) { re.pts[i] = Vector2f(out_pts[2 * i], out_pts[2 * i + 1]); ++cnt[sg[i]]; }
+        re.positions.clear();
+        for (int s = 0, o = 0; s < S; ++s) {
+            VectorXf v = VectorXf::Zero(cnt[s]);
+            for (int k = 0; k < cnt[s]; ++k) v(k) = tp[o + k];
+            o += cnt[s];
+            re.positions.push_back(std::move(v));
+        }
+        return re;
+    }
+
+    // signed curvature at every sample of `positions` (same as :1017-1039: hodograph and its hodograph)
+    std::vector<float> curvature(gpu_context& ctx = default_context()) const {
+        const int S = n_segments();
+        std::vector<float> c(8 * (size_t)S), t;
+        std::vector<int32_t> sg;
+        for (int i = 0; i < S; ++i)
+            for (int k = 0; k < 4; ++k) { c[8 * i + 2 * k] = ctrl_pts[i][k].x(); c[8 * i + 2 * k + 1] = ctrl_pts[i][k].y(); }
+        for (int s = 0; s < (int)positions.size(); ++s)
+            for (size_t k = 0; k < (size_t)positions[s].rows(); ++k) { t.push_back(positions[s](k)); sg.push_back(s); }
+        const int M = (int)t.size();
+        std::vector<float> res(M);
+        if (M == 0) return res;
+        std::vector<float> d1(2 * (size_t)M), d2(2 * (size_t)M);
+        ctx.check(sc_bezier_eval_batch_host(ctx.get(), c.data(), S, sg.data(), t.data(), M, 1, d1.data()), "sc_bezier_eval_batch_host");
+        ctx.check(sc_bezier_eval_batch_host(ctx.get(), c.data(), S, sg.data(), t.data(), M, 2, d2.data()), "sc_bezier_eval_batch_host");
+        for (int i = 0; i < M; ++i) {
+            const float dx = d1[2 * i], dy = d1[2 * i + 1], ddx = d2[2 * i], ddy = d2[2 * i + 1];
+            res[i] = (dx * ddy - dy * ddx) / std::pow(dx * dx + dy * dy, 1.5f);
+        }
+        return res;
+    }
+
+    inline std::vector<float> angular_velocity(const velocity_profile& vel_prof) const;   // :1055-1067
 };
 
 // ---- velocity profile (sea_current.hpp:379-386, 1172-1265) ------------------------------------------
@@ -415,6 +486,14 @@ struct velocity_profile {
     velocity_profile(std::vector<VectorXf> pos, std::vector<VectorXf> vel, std::vector<VectorXf> acc, toppra_compat::Vector time)
         : pos(std::move(pos)), vel(std::move(vel)), acc(std::move(acc)), time(std::move(time)) {}
 };
+
+inline std::vector<float> bezier_spline::angular_velocity(const velocity_profile& vel_prof) const {
+    const std::vector<float> curv = curvature();
+    SC_ASSERT(curv.size() == (size_t)vel_prof.vel[0].size(), "curvature and velocity vectors must be the same size");
+    std::vector<float> w(curv.size());
+    for (size_t i = 0; i < w.size(); ++i) w[i] = vel_prof.vel[0](i) * curv[i];
+    return w;
+}
 
 // limits as a function of the GRIDPOINT value s in [0,1] (the reference names the argument "time", :1175, :1185)
 using vel_lim_func = std::function<std::tuple<toppra_compat::Vector, toppra_compat::Vector>(value_type time)>;

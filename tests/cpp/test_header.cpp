@@ -68,6 +68,26 @@ int main() {
     for (int i = 0; i < 4328; ++i) { vmax = std::max(vmax, prof.vel[0](i)); amax = std::max(amax, std::fabs(prof.acc[0](i))); }
     CHECK(std::fabs(vmax - 0.253140f) < 2e-6f);                     // BASELINE.md extrema
     CHECK(std::fabs(amax - 0.497336f) < 2e-6f);
+    // --- resample + angular velocity: examples/zmq_test.cpp:91-93 -------------------------------------
+    {
+        const bounding_rect br2 = {10, -10, 10, -10};
+        planning_space free_space(br2);
+        bezier_spline pad = bezier_spline::from_path({Vector2f(0, 0), Vector2f(10, 0), Vector2f(10, 10)}, free_space);
+        const arclength_data ad = pad.arclength();
+        velocity_profile prof2 = gen_vel_prof<1>(VectorNd<1>{ad.arclength}, VectorNd<1>{0}, VectorNd<1>{0}, VectorNd<1>{0}, vel_lim,
+                                                 VectorNd<1>{-0.5}, VectorNd<1>{0.5});
+        bezier_spline re = pad.resample(prof2.pos[0], ad, true);
+        CHECK(re.n_pts() == (int)prof2.pos[0].rows() && re.n_pts() == 4328);
+        CHECK(prof2.pos[0](0) == 0.0f && prof2.pos[0](4327) == ad.arclength);   // the nudge pins the ends (:903-904)
+        float xmax = -1e9f, ymin = 1e9f;
+        for (const auto& p : re.pts) { xmax = std::max(xmax, p.x()); ymin = std::min(ymin, p.y()); }
+        CHECK(std::fabs(re.pts[0].x() - 0.00401974f) < 2e-5f && std::fabs(re.pts[4327].x() - 9.999999f) < 2e-5f && std::fabs(re.pts[4327].y() - 9.9983425f) < 2e-5f);   // output.json: pos_x/pos_y ends (the fit misses t = 0 by 2.7e-4)
+        CHECK(std::fabs(xmax - 11.571348f) < 5e-5f && std::fabs(ymin + 1.5713487f) < 5e-5f);   // output.json: pos_x max, pos_y min
+        const std::vector<float> w = re.angular_velocity(prof2);
+        float wmax = 0;
+        for (float v : w) wmax = std::max(wmax, std::fabs(v));
+        CHECK(w.size() == 4328 && std::fabs(wmax - 0.08215085f) < 2e-6f);                      // output.json: max |ang_vel|
+    }
     std::printf("sea_current.hpp: planning path + velocity profile OK (%zu waypoints, %d samples)\n", path->size(), 4328);
     return 0;
 }

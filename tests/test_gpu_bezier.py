@@ -64,3 +64,93 @@ def test_eval_orders(ctx, oracle):
         torch.cuda.synchronize()
         ref = oracle.bezier_eval(ctrl, seg, t.astype(np.float64), order)
         assert np.allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-6), order
+
+
+def test_resample_fixture_pipeline(ctx, oracle, golden_dir):
+    """The whole recorded run of the reference (examples/zmq_test.cpp:66-93) on the GPU: waypoints -> from_path ->
+    arclength -> TOPP-RA (1 dof along the arclength) -> sampling -> resample(nudge) -> angular velocity, against
+    examples/output.json (pos_x / pos_y / ang_vel)."""
+    import torch
+    fx = np.load(os.path.join(golden_dir, "toppra_1dof_output.npz"))
+    dev = "cuda"
+    ctrl = ctx.bezier_from_path(torch.from_numpy(fx["waypoints"][None].copy()).to(dev), torch.tensor([3], dtype=torch.int32, device=dev))
+    cum, seg_len = ctx.bezier_arclength(ctrl, 100)
+    AL = seg_len.sum().reshape(1)
+    N = 100
+    f64 = lambda v: torch.tensor([[v]], dtype=torch.float64, device=dev)
+    vlo = torch.full((1, N + 1, 1), float(fx["vel_lim"][0]), dtype=torch.float64, device=dev)
+    vhi = torch.full((1, N + 1, 1), float(fx["vel_lim"][1]), dtype=torch.float64, device=dev)
+    p0, p1, v0, v1 = f64(0.0), AL.double().reshape(1, 1), f64(0.0), f64(0.0)
+    res = ctx.toppra(p0, p1, v0, v1, vlo, vhi, f64(float(fx["acc_lim"][0])), f64(float(fx["acc_lim"][1])), N=N)
+    smp = ctx.toppra_sample(p0, p1, v0, v1, res["x"], res["t"], float(np.float32(0.02)), max_len=4400)
+    L = int(smp["length"][0])
+    assert L == fx["pos"].shape[0]
+    pos = smp["pos"][0, 0, :L].contiguous()
+    off = torch.tensor([0, L], dtype=torch.int32, device=dev)
+    out = ctx.bezier_resample(ctrl.reshape(-1, 4, 2), cum, AL, torch.tensor([0, 2], dtype=torch.int32, device=dev), pos, off, nudge=True)
+    torch.cuda.synchronize()
+    assert int(out["status"][0]) == 0
+    pts = out["pts"].cpu().numpy()
+    assert np.abs(pts[:, 0] - fx["pos_x"]).max() < 5e-5 and np.abs(pts[:, 1] - fx["pos_y"]).max() < 5e-5
+    ang = (smp["vel"][0, 0, :L] * out["curvature"]).cpu().numpy()
+    assert np.abs(ang - fx["ang_vel"]).max() < 2e-6
+    # and from the recorded profile itself: same bar as the oracle
+    pos2 = torch.from_numpy(fx["pos"].copy()).to(dev)
+    out2 = ctx.bezier_resample(ctrl.reshape(-1, 4, 2), torch.from_numpy(fx["arclength_segments"].copy()).to(dev),
+                               torch.tensor([float(fx["arclength"])], dtype=torch.float32, device=dev),
+                               torch.tensor([0, 2], dtype=torch.int32, device=dev), pos2, off, nudge=True)
+    torch.cuda.synchronize()
+    ref = oracle.bezier_resample(ctrl.cpu().numpy().reshape(-1, 4, 2), fx["arclength_segments"], fx["arclength"], fx["pos"], True)
+    assert np.array_equal(pos2.cpu().numpy(), ref["pos"]) and np.array_equal(out2["seg"].cpu().numpy(), ref["seg"])
+    assert np.abs(out2["t"].cpu().numpy() - ref["t"]).max() < 2e-7
+    assert np.abs(out2["pts"].cpu().numpy() - ref["pts"]).max() < 2e-6
+    assert np.abs(out2["pts"].cpu().numpy()[:, 0] - fx["pos_x"]).max() < 2e-5
+    assert np.abs(fx["vel"] * out2["curvature"].cpu().numpy() - fx["ang_vel"]).max() < 3e-7
+
+
+def test_resample_batch_matches_oracle(ctx, oracle):
+    """Ragged batch: 1..7 segments, glitchy profiles (the nudge's sequential replay path), with and without nudge."""
+    import torch
+    rng = np.random.default_rng(21)
+    B, nsub = 23, 64
+    ctrls, cums, als, pps, seg_off, prof_off = [], [], [], [], [0], [0]
+    for b in range(B):
+        nwp = int(rng.integers(2, 9))
+        path = np.cumsum(rng.uniform(0.5, 3.0, (nwp, 2)) * rng.choice([-1, 1], (nwp, 2)), axis=0).astype(np.float32)
+        c = oracle.bezier_from_path(path)
+        tot, cum = oracle.bezier_arclength(c, nsub)
+        cum = cum.astype(np.float32)
+        AL = np.float32(cum[:, -1].sum(dtype=np.float32))
+        n = int(rng.integers(40 * (nwp - 1), 400))
+        pp = (np.sort(rng.uniform(0, 1, n)) * AL).astype(np.float32)
+        if b % 3 != 2:                                           # leave some profiles clean
+            k = rng.choice(np.arange(1, n - 1), max(1, n // 30), replace=False)
+            pp[k] += rng.normal(0, 0.05 * AL, k.size).astype(np.float32)
+        ctrls.append(c); cums.append(cum); als.append(AL); pps.append(pp)
+        seg_off.append(seg_off[-1] + nwp - 1); prof_off.append(prof_off[-1] + n)
+    dev = "cuda"
+    tc = torch.from_numpy(np.concatenate(ctrls)).to(dev)
+    tcum = torch.from_numpy(np.concatenate(cums)).to(dev)
+    tal = torch.tensor(np.array(als), dtype=torch.float32, device=dev)
+    tso = torch.tensor(seg_off, dtype=torch.int32, device=dev)
+    tpo = torch.tensor(prof_off, dtype=torch.int32, device=dev)
+    for nudge in (True, False):
+        tpp = torch.from_numpy(np.concatenate(pps)).to(dev)
+        out = ctx.bezier_resample(tc, tcum, tal, tso, tpp, tpo, nudge=nudge)
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in out.items()}
+        gpp = tpp.cpu().numpy()
+        for b in range(B):
+            if not nudge and b % 3 != 2:
+                continue                                         # glitchy profile without the nudge: the reference asserts
+            ref = oracle.bezier_resample(ctrls[b], cums[b], als[b], pps[b], nudge)
+            sl = slice(prof_off[b], prof_off[b + 1])
+            assert got["status"][b] == ref["status"], b
+            assert np.array_equal(gpp[sl], ref["pos"]), b
+            if ref["status"]:
+                continue
+            assert np.array_equal(got["seg"][sl], ref["seg"]), b
+            assert np.abs(got["t"][sl] - ref["t"]).max() < 5e-7, b
+            assert np.abs(got["pts"][sl] - ref["pts"]).max() < 1e-5, b
+            k = np.abs(ref["curvature"]) < 1e3                   # cusps of random splines: compare where curvature is sane
+            assert np.allclose(got["curvature"][sl][k], ref["curvature"][k], rtol=2e-4, atol=1e-5), b

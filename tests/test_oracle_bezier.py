@@ -51,3 +51,55 @@ def test_straight_path_arclength_is_length(oracle):
     path = np.array([[0, 0], [3, 4]], np.float32)
     total, cum = oracle.bezier_arclength(oracle.bezier_from_path(path), 100)
     assert abs(total - 5.0) < 1e-9 and abs(cum[0, -1] - 5.0) < 1e-9
+
+
+def test_resample_fixture(oracle, golden_dir):
+    """resample(prof.pos[0], ad, true) + angular_velocity of the recorded run (examples/zmq_test.cpp:91-93): the JSON's
+    pos_x / pos_y and ang_vel are reproduced from its `pos` and `vel` series."""
+    fx = np.load(os.path.join(golden_dir, "toppra_1dof_output.npz"))
+    ctrl = oracle.bezier_from_path(fx["waypoints"])
+    r = oracle.bezier_resample(ctrl, fx["arclength_segments"], fx["arclength"], fx["pos"], nudge=True)
+    assert r["status"] == 0
+    assert np.array_equal(r["pos"], fx["pos"])                  # the recorded series is already the nudged one
+    assert np.abs(r["pts"][:, 0] - fx["pos_x"]).max() < 2e-5    # coordinates up to 11: 1e-6 relative (float32 fit upstream)
+    assert np.abs(r["pts"][:, 1] - fx["pos_y"]).max() < 2e-5
+    assert np.abs(fx["vel"] * r["curvature"] - fx["ang_vel"]).max() < 3e-7
+    assert np.bincount(r["seg"]).tolist() == [2164, 2164]       # boundary sample duplicated, last sample dropped (:938-993)
+    # same through the oracle's own arclength tables
+    tot, cum = oracle.bezier_arclength(ctrl, 100)
+    r2 = oracle.bezier_resample(ctrl, cum.astype(np.float32), np.float32(tot), fx["pos"], nudge=True)
+    assert np.abs(r2["pts"] - np.stack([fx["pos_x"], fx["pos_y"]], 1)).max() < 2e-5
+
+
+def test_resample_nudge_and_split(oracle):
+    """nudge semantics (:902-913) and the overlapping split on a 4-segment spline, against a literal numpy replay."""
+    rng = np.random.default_rng(12)
+    path = np.array([[0, 0], [3, 1], [5, 4], [9, 3], [12, 6]], np.float32)
+    ctrl = oracle.bezier_from_path(path)
+    tot, cum = oracle.bezier_arclength(ctrl, 40)
+    cum = cum.astype(np.float32)
+    AL = np.float32(cum[:, -1].sum())
+    n = 700
+    pp = (np.linspace(0, 1, n) ** 1.3 * AL).astype(np.float32)
+    bad = rng.choice(np.arange(2, n - 2), 25, replace=False)
+    pp[bad] += rng.normal(0, 0.4, 25).astype(np.float32)       # non-monotone glitches, some beyond [0, AL]
+    pp[5] = -1.0
+    pp[n - 4] = AL + 1
+    ref = pp.copy()
+    ref[0] = 0; ref[-1] = AL
+    for i in range(1, n - 1):
+        if ref[i] < ref[i - 1] or ref[i] > ref[i + 1]:
+            ref[i] = (ref[i - 1] + ref[i + 1]) / np.float32(2)
+        ref[i] = min(max(ref[i], np.float32(0)), AL)
+    r = oracle.bezier_resample(ctrl, cum, AL, pp, nudge=True)
+    assert r["status"] == 0 and np.array_equal(r["pos"], ref)
+    assert np.all(np.diff(r["seg"]) >= 0) and r["seg"][0] == 0 and r["seg"][-1] == 3
+    assert np.all((r["t"] >= 0) & (r["t"] <= 1))
+    # points lie on the curve at the reported parameter, and their arclength position tracks the profile
+    p = oracle.bezier_eval(ctrl, r["seg"], r["t"].astype(np.float64))
+    assert np.abs(p - r["pts"]).max() < 1e-6
+    lens = cum[:, -1].astype(np.float64)
+    tk = np.arange(41) / 40
+    s_of = np.array([lens[:g].sum() + np.interp(t, tk, cum[g]) for g, t in zip(r["seg"], r["t"])])
+    want = np.concatenate([ref[:1], ref]).astype(np.float64)[np.arange(n) - r["seg"] + 1]   # output o of segment i is sample o - i
+    assert np.abs(s_of - want).max() < 0.02 * AL
