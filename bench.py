@@ -29,6 +29,11 @@ for _p in (ROOT, os.path.join(ROOT, "sea-current_amd", "python")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# Independent steps are pipelined on separate HIP streams (--depth).  The HIP runtime multiplexes a process's streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels that share a queue run one after the other; an A*
+# batch ends with its slowest query, so 4 concurrent batches leave most SIMDs idle.  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 
@@ -53,14 +58,14 @@ def make_grid(name, W, H):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--map", default="salt20", choices=list(FAMILIES),
                     help="obstacle family of the headline numbers (the other two are reported under other_maps)")
     ap.add_argument("--only-main-map", action="store_true")
-    ap.add_argument("--depth", type=int, default=4,
+    ap.add_argument("--depth", type=int, default=16,
                     help="independent steps in flight (own context/stream each); 1 = strictly sequential steps")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
@@ -69,6 +74,8 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the "
                          "multi-rank control flow with several ranks on one GPU: results are gathered through host copies)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--replan-frames", type=int, default=20,
+                    help="frames of the dynamic-obstacle replan stream (BASELINE configs[4]) timed at N=1; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,7 +233,8 @@ def main():
             "config": {"workload": f"{W}x{H} random-obstacle grid ({args.map}), EDT + A*, {Qloc} batched queries per GPU"
                                    + (", RCCL all-gather of paths" if world > 1 else ""),
                        "grid": [W, H], "map": args.map, "queries_per_gpu": Qloc, "queries_total": Qtot, "lmax": args.lmax,
-                       "parallelism": f"query-sharded x{world}", "pipeline_depth": depth_max},
+                       "parallelism": f"query-sharded x{world}", "pipeline_depth": depth_max,
+                                  "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "latency_ms_per_step_sequential": seq_run["ms_per_step"], "value_sequential": seq_run["value"],
             "step_kernels": main_run["step_kernels"], "astar": main_run["astar"],
             "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"], "astar_ms_per_step": r["step_kernels"]["astar"]["ms_per_step"],
@@ -268,7 +276,7 @@ def main():
         legs = {fam: edt_leg(fam) for fam in ("salt05", "salt20", "blocks")}
         result["roofline"] = legs[args.map]
         tpath = os.path.join(ROOT, "profiles", "edt_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (W, H, args.edt_batch) == (1024, 1024, 64):
             try:
                 result["roofline"]["traffic"] = json.load(open(tpath)).get(args.map, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -300,6 +308,38 @@ def main():
                             "plans_per_s": P / ((ms_t + ms_s) / 10 * 1e-3), "algorithmic_GBps": tbytes / (ms_t / 10 * 1e-3) / 1e9,
                             "hbm_frac": tbytes / (ms_t / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "latency-bound (two dependent 200-stage sweeps per plan), not HBM-bound"}
+
+    # ---- dynamic-obstacle replan stream (BASELINE configs[4]), N = 1 only: reported, not part of `value` ----
+    if rank == 0 and world == 1 and args.replan_frames > 0:
+        rects = synth.block_rects(W, H)
+        occ0 = synth.raster_rects(rects, W, H)
+        frames = [rects]
+        for f in range(1, args.replan_frames + 2):
+            frames.append(synth.move_rects(frames[-1], f, W, H))
+        frames_dev = [torch.from_numpy(r).to(dev) for r in frames]
+        occ_dev = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        replan = {"map": "blocks (256 rectangles, 32 moved by <= 2 cells per frame)", "frames": args.replan_frames}
+        for Qf in (8192, 8192 // 8):
+            sf, gf = synth.queries(occ0 == 0, Qf)
+            sfd, gfd = torch.from_numpy(sf).to(dev), torch.from_numpy(gf).to(dev)
+
+            def frame(i):
+                ctx.occ_from_rects(frames_dev[i], W, H, out=occ_dev)
+                d2f = ctx.edt(occ_dev)
+                return ctx.astar_batch(d2f, sfd, gfd, Lmax=args.lmax)
+            frame(0)
+            frame(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.replan_frames):
+                of = frame(2 + i)
+                torch.cuda.synchronize()            # a frame's paths are due before the next frame arrives
+            ms = (time.perf_counter() - t0) / args.replan_frames * 1e3
+            replan[f"q{Qf}"] = {"queries_per_frame": Qf, "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "meets_30hz": ms < 1e3 / 30,
+                                "found_last_frame": int((of["status"] == 0).sum())}
+        replan["note"] = ("per frame: rectangle list -> occupancy grid, full exact EDT, legal moves, batched A*, synchronised; "
+                          "q8192 = the whole 8k-query frame on ONE GPU, q1024 = one GPU's share when 8 GPUs split the frame")
+        result["replan_stream"] = replan
 
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

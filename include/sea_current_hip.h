@@ -61,7 +61,8 @@ typedef enum {
     SC_K_BEZIER = 6,      /* tangents + control points, curve evaluation */
     SC_K_ARCLENGTH = 7,   /* GL-32 arclength tables */
     SC_K_RESAMPLE = 8,    /* resample: nudge + split, Chebyshev fit + evaluation */
-    SC_K_COUNT = 9
+    SC_K_OCC = 9,         /* occupancy grid from a rectangle list (dynamic-obstacle frames) */
+    SC_K_COUNT = 10
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -101,6 +102,13 @@ int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes);
  * mathematically (oracle/sc_oracle.h). */
 int sc_edt_u8_i32(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
 int sc_edt_u8_i32_host(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
+
+/* Occupancy grid of a frame of the dynamic-obstacle replan loop (BASELINE.json configs[4]): occ = base (or all free
+ * when base is NULL; base == occ paints in place) with R cell rectangles (x0, y0, x1, y1; x1/y1 exclusive; clipped)
+ * painted as occupied; free_border != 0 keeps the outermost ring of cells free.  Stands where the
+ * reference edits planning_space::obstacles (sea_current.hpp:314) between plans; the EDT is then recomputed in full
+ * by sc_edt_u8_i32 (exact, ~10 us at 1024^2).  Device pointers; rects int32 [R][4]. */
+int sc_occ_from_rects(sc_ctx* ctx, const uint8_t* base, const int32_t* rects, int R, int W, int H, int free_border, uint8_t* occ);
 
 /* Legal-move mask per cell: bit d set iff move d (dx={1,-1,0,0,1,-1,1,-1},
  * dy={0,0,1,-1,1,1,-1,-1}) out of the cell is allowed: both cells have

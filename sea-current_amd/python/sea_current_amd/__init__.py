@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE = range(9)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC = range(10)
 
 _lib = None
 
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_sample_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
     "sc_toppra_sample_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+    "sc_occ_from_rects": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_eval_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -247,6 +248,14 @@ class Context:
                                                 _ptr(out["acc"]), _ptr(out["time"]), _ptr(out["length"])),
                  "sc_toppra_sample_batch")
         return out
+
+    def occ_from_rects(self, rects, W, H, base=None, free_border=True, out=None):
+        """rects int32 [R,4] (x0,y0,x1,y1 exclusive; GPU) painted over `base` uint8 [H,W] (or an empty grid) -> occ uint8 [H,W]."""
+        import torch
+        occ = out if out is not None else torch.empty((H, W), dtype=torch.uint8, device=rects.device)
+        self._ck(self._l.sc_occ_from_rects(self._h, _ptr(base) if base is not None else None, _ptr(rects), rects.shape[0], W, H,
+                                           1 if free_border else 0, _ptr(occ)), "sc_occ_from_rects")
+        return occ
 
     def bezier_from_path(self, path, npts, start_angle=float("nan"), lines=None):
         """path float32 [P,n_max,2], npts int32 [P] (GPU) -> ctrl float32 [P,n_max-1,4,2]."""

@@ -38,21 +38,52 @@ def salt_grid(W, H, p=0.05, seed=SEED_GRID):
     return _free_border((u < p).astype(np.uint8))
 
 
-def block_grid(W, H, coverage=0.20, seed=SEED_GRID, smin=4, smax=64):
-    """Random axis-aligned rectangles (side smin..smax) until >= coverage, borders free."""
+def block_rects(W, H, coverage=0.20, seed=SEED_GRID, smin=4, smax=64):
+    """The rectangle list behind block_grid: int32 [R,4] = (x0, y0, x1, y1), x1/y1 exclusive, clipped to the grid."""
     occ = np.zeros((H, W), dtype=np.uint8)
     target = int(coverage * W * H)
-    i = 0
+    rects = []
     covered = 0
     while covered < target:
+        i = len(rects)
         r = _u01(seed ^ 0xB10C, np.arange(4 * i, 4 * i + 4, dtype=np.uint64))
         w = smin + int(r[0] * (smax - smin + 1)); h = smin + int(r[1] * (smax - smin + 1))
         x0 = int(r[2] * W); y0 = int(r[3] * H)
         occ[y0:y0 + h, x0:x0 + w] = 1
-        i += 1
-        if i % 64 == 0 or covered == 0:
+        rects.append((x0, y0, min(x0 + w, W), min(y0 + h, H)))
+        if len(rects) % 64 == 0 or covered == 0:
             covered = int(occ.sum())
-    return _free_border(occ)
+    return np.array(rects, dtype=np.int32)
+
+
+def raster_rects(rects, W, H, base=None, free_border=True):
+    """occ uint8 [H,W]: `base` (or an empty grid) with the rectangles painted as occupied, borders free."""
+    occ = np.zeros((H, W), dtype=np.uint8) if base is None else np.array(base, dtype=np.uint8)
+    for x0, y0, x1, y1 in np.asarray(rects).tolist():
+        occ[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)] = 1
+    return _free_border(occ) if free_border else occ
+
+
+def block_grid(W, H, coverage=0.20, seed=SEED_GRID, smin=4, smax=64):
+    """Random axis-aligned rectangles (side smin..smax) until >= coverage, borders free."""
+    return raster_rects(block_rects(W, H, coverage, seed, smin, smax), W, H)
+
+
+def move_rects(rects, frame, W, H, K=32, step=2, seed=SEED_GRID):
+    """Frame `frame` of the dynamic-obstacle stream: K of the rectangles (chosen by hash of the frame
+    number) move by at most `step` cells in x and y, staying inside the grid.  Returns the new list; frames are applied
+    one after the other starting from block_rects()."""
+    out = np.array(rects, dtype=np.int32)
+    R = out.shape[0]
+    h = splitmix64(np.uint64(seed ^ 0xD1A) ^ splitmix64(np.uint64(frame) * np.uint64(3 * K) + np.arange(3 * K, dtype=np.uint64)))
+    for k in range(min(K, R)):
+        i = int(h[3 * k] % np.uint64(R))
+        dx = int(h[3 * k + 1] % np.uint64(2 * step + 1)) - step
+        dy = int(h[3 * k + 2] % np.uint64(2 * step + 1)) - step
+        x0, y0, x1, y1 = out[i]
+        dx = max(-x0, min(dx, W - x1)); dy = max(-y0, min(dy, H - y1))
+        out[i] = (x0 + dx, y0 + dy, x1 + dx, y1 + dy)
+    return out
 
 
 def largest_component(trav):

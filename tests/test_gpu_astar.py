@@ -98,3 +98,22 @@ def test_astar_host_entry_point(ctx, oracle):
     s, g = synth.queries(d2 >= 1, 20, seed=8)
     ref = oracle.astar_batch(d2, s, g, Lmax=512)
     _compare(ctx.astar_batch_host(d2, s, g, Lmax=512), ref, 20)
+
+
+def test_astar_4096_config3(ctx, oracle):
+    """BASELINE configs[3] shape (4096^2 grid; one rank's slice of the 64k queries, cut to what the oracle checks in
+    seconds): GPU EDT + A* vs the oracle, bit-exact, and the query generator's rank-independent indexing."""
+    import torch
+    from sea_current_amd import synth
+    occ = synth.salt_grid(4096, 4096, 0.20)
+    d2 = ctx.edt(torch.from_numpy(occ).cuda())
+    torch.cuda.synchronize()
+    d2h = d2.cpu().numpy()
+    assert np.array_equal(d2h, oracle.edt(occ))
+    trav = d2h >= 1
+    s, g = synth.queries(trav, 64, first=8192 * 3)              # the first queries of rank 3 of 8
+    out = ctx.astar_batch(d2, torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), Lmax=16384)
+    torch.cuda.synchronize()
+    ref = oracle.astar_batch(d2h, s, g, Lmax=16384, nthreads=16)
+    _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 64)
+    assert (ref["status"] == 0).all() and ref["len"].max() > 2048
