@@ -58,6 +58,7 @@ struct astar_args {
     int32_t* expanded;  // [Q]
     int32_t* dbg;       // [Q][2] sub-iterations, kilo-cycles (may be null)
     const int32_t* redo;  // optional: only run queries whose status == Q_OVERFLOW
+    int tw;               // g layout: 4 x 4-cell tiles (one 64-byte sector each), tw tiles per tile row
     uint32_t epoch_tag;   // epoch << shift
     uint32_t gmask;       // (1 << shift) - 1, or 0xFFFFFFFF when epochs are off
 };
@@ -66,6 +67,14 @@ __device__ __forceinline__ int octile(int x, int y, int gx, int gy) {
     int dx = abs(x - gx), dy = abs(y - gy);
     return 10 * max(dx, dy) + 4 * min(dx, dy);
 }
+
+// Index of cell (x, y) in a query's g array.  The array is laid out in tiles of 4 x 4 cells = one 64-byte sector, so
+// the 3 x 3 neighbourhood of a node touches 2.25 sectors on average instead of 3.4 with rows of W cells; the rate of
+// L2-missing atomics is what bounds a full chip (tools/microbench/relax_mb.hip: +36 % steps/s with this layout).
+// The two halves are additive: gix = g_xpart(x) + g_ypart(y).
+__device__ __forceinline__ uint32_t g_xpart(int x) { return ((uint32_t)(x >> 2) << 4) | (uint32_t)(x & 3); }
+__device__ __forceinline__ uint32_t g_ypart(int y, int tw) { return (((uint32_t)(y >> 2) * (uint32_t)tw) << 4) | ((uint32_t)(y & 3) << 2); }
+__device__ __forceinline__ uint32_t gix(int x, int y, int tw) { return g_xpart(x) + g_ypart(y, tw); }
 
 __device__ __forceinline__ uint32_t g_load(const uint32_t* p) {
     // agent-scope relaxed load: served by L2, where this wave's atomicMin results live
@@ -141,11 +150,18 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     const uint32_t etag = a.epoch_tag, gmask = a.gmask;
 
     int dbg_iter = 0;
+#ifdef ASTAR_COUNT_POPS
+    int dbg_pops = 0;
+#endif
     unsigned long long dbg_t0 = 0;
     auto finish = [&](int st, int ln, int cs, int ex) {
         if (lane == 0) {
             a.status[q] = st; a.len[q] = ln; a.cost[q] = cs; a.expanded[q] = ex;
+#ifdef ASTAR_COUNT_POPS
+            if (a.dbg) { a.dbg[2 * q] = dbg_iter; a.dbg[2 * q + 1] = dbg_pops; }
+#else
             if (a.dbg) { a.dbg[2 * q] = dbg_iter; a.dbg[2 * q + 1] = (int)((__builtin_amdgcn_s_memtime() - dbg_t0) >> 10); }
+#endif
         }
     };
     if (s < 0 || t < 0 || (size_t)s >= cells || (size_t)t >= cells || a.d2[s] < a.rmin || a.d2[t] < a.rmin) {
@@ -157,7 +173,8 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         finish(SC_Q_OK, 1, 0, 0);
         return;
     }
-    uint32_t* g = a.g + (size_t)slot * cells;
+    const int tw = a.tw;
+    uint32_t* g = a.g + (size_t)slot * ((size_t)tw * ((H + 3) >> 2) * 16);
     uint32_t* bk = a.buckets + (size_t)slot * NBUCKET * a.cap;
     const int cap = a.cap, capm = a.cap - 1;
     const int sx = s % W, sy = s / W, gx = t % W, gy = t / W;
@@ -180,7 +197,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     if (lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
     int fcur = octile(sx, sy, gx, gy);
     if (lane == 0) {
-        __hip_atomic_store(&g[s], etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
+        __hip_atomic_store(&g[gix(sx, sy, tw)], etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
         qxy[0] = (uint32_t)(sy << 16 | sx);
         qmv[0] = a.moves[s];
     }
@@ -213,6 +230,9 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
             }
             const int K = (n + 7) >> 3;  // groups of 8 nodes (x 8 moves = 64 lanes)
             ++niter;
+#ifdef ASTAR_COUNT_POPS
+            dbg_pops += n;
+#endif
             // The step is instantiated for 1, 2, 4 or 8 groups: narrow frontiers (the common case on
             // dense maps) then run ~1/8 of the instructions of a full 64-node step.
             auto step = [&](auto km_tag) {
@@ -245,7 +265,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                             const uint32_t e = bq[(hd + 8 * k + sub) & capm];
                             cx[k] = e & 0x1FFF; de[k] = (e >> 13) & 7; cy[k] = e >> 16;
                             const int c = cy[k] * W + cx[k];
-                            gv[k] = g_load(&g[c]);
+                            gv[k] = g_load(&g[gix(cx[k], cy[k], tw)]);
                             mm[k] = a.moves[c];
                             valid[k] = true;
                         }
@@ -272,7 +292,8 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     legal[0] = valid[0] && ((mv[0] >> d) & 1);
                     if (legal[0]) {
                         const int nidx = cy[0] * W + cx[0] + moff;
-                        old[0] = __hip_atomic_fetch_min(&g[nidx], etag | (gc[0] + mw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        old[0] = __hip_atomic_fetch_min(&g[gix(cx[0] + mdx, cy[0] + mdy, tw)], etag | (gc[0] + mw), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
                         nmv[0] = a.moves[nidx];
                     }
                 } else {
@@ -282,7 +303,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     for (int k = 0; k < KM; ++k) {
                         legal[k] = valid[k] && ((mv[k] >> d) & 1);
                         const int nidx = legal[k] ? cy[k] * W + cx[k] + moff : 0;
-                        ad[k] = &g[nidx];
+                        ad[k] = &g[legal[k] ? gix(cx[k] + mdx, cy[k] + mdy, tw) : 0u];
                         dv[k] = legal[k] ? (etag | (gc[k] + mw)) : 0xFFFFFFFFu;
                         old[k] = 0;
                         nmv[k] = a.moves[nidx];   // plain loads: unconditional is harmless
@@ -354,7 +375,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     if (lane < n) {
                         const uint32_t e = bq[(hd + lane) & capm];
                         cx = e & 0x1FFF; de = (e >> 13) & 7; cy = e >> 16;
-                        gv = g_load(&g[cy * W + cx]);
+                        gv = g_load(&g[gix(cx, cy, tw)]);
                         mm = a.moves[cy * W + cx];
                         valid = true;
                     }
@@ -370,11 +391,13 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                 const int off8[8] = {1, -1, W, -W, W + 1, W - 1, -W + 1, -W - 1};
                 uint32_t old[8], nmv[8], dv[8];
                 uint32_t* ad[8];
+                const uint32_t xp[3] = {g_xpart(cx - 1), g_xpart(cx), g_xpart(cx + 1)};
+                const uint32_t yp[3] = {g_ypart(cy - 1, tw), g_ypart(cy, tw), g_ypart(cy + 1, tw)};
 #pragma unroll
                 for (int dd = 0; dd < 8; ++dd) {
                     const bool lg = (mv >> dd) & 1;
                     const int nidx = lg ? c + off8[dd] : 0;
-                    ad[dd] = &g[nidx];
+                    ad[dd] = &g[lg ? xp[ddx[dd] + 1] + yp[ddy[dd] + 1] : 0u];
                     dv[dd] = lg ? (etag | (gc + (dd < 4 ? 10u : 14u))) : 0xFFFFFFFFu;
                     old[dd] = 0;
                     nmv[dd] = a.moves[nidx];   // plain loads: unconditional is harmless
@@ -453,7 +476,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
             if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
                 const int n = ny * W + nx;
                 if ((a.moves[n] >> d) & 1) {
-                    const uint32_t gn = g_load(&g[n]);
+                    const uint32_t gn = g_load(&g[gix(nx, ny, tw)]);
                     ok = gn == (etag | (gc - (d < 4 ? 10u : 14u)));  // tagged and g[n] + w == g[c]
                 }
             }
@@ -483,10 +506,10 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
 }
 
 // strip the epoch tags of one slot: canonical g field (0xFFFFFFFF = unreached)
-__global__ void __launch_bounds__(256) gfield_untag_kernel(const uint32_t* g, size_t cells, uint32_t etag, uint32_t gmask, uint32_t* out) {
+__global__ void __launch_bounds__(256) gfield_untag_kernel(const uint32_t* g, int W, int H, int tw, uint32_t etag, uint32_t gmask, uint32_t* out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < cells) {
-        const uint32_t v = g[i];
+    if (i < (size_t)W * H) {
+        const uint32_t v = g[gix((int)(i % W), (int)(i / W), tw)];
         out[i] = (v & ~gmask) == etag && (gmask != 0xFFFFFFFFu || v != 0xFFFFFFFFu) ? (v & gmask) : 0xFFFFFFFFu;
     }
 }
@@ -495,6 +518,8 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
                      const int32_t* goal, int Q, int Lmax, int32_t* path, int32_t* len, int32_t* cost,
                      int32_t* status) {
     const size_t cells = (size_t)W * H;
+    const int tw = (W + 3) >> 2;
+    const size_t gcells = (size_t)tw * ((H + 3) >> 2) * 16;   // g array: whole 4 x 4 tiles
     const int32_t rmin = r2 > 1 ? r2 : 1;
     int r = sc_scratch_reserve(ctx, &ctx->moves, cells);
     if (r != SC_OK) return r;
@@ -509,11 +534,11 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
     int cap = ctx->astar_cap;
     const int32_t* redo = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        const size_t per_slot = cells * 4 + (size_t)NBUCKET * cap * 4;
+        const size_t per_slot = gcells * 4 + (size_t)NBUCKET * cap * 4;
         size_t slots = ctx->astar_slot_budget / per_slot;
         if (slots < 1) slots = 1;
         if (slots > (size_t)Q) slots = Q;
-        const size_t g_bytes = slots * cells * 4;
+        const size_t g_bytes = slots * gcells * 4;
         if (g_bytes > ctx->gslots.bytes || shift != ctx->astar_shift) ctx->astar_epoch = 0;  // fresh or re-laid-out memory
         r = sc_scratch_reserve(ctx, &ctx->gslots, g_bytes);
         if (r != SC_OK) return r;
@@ -540,7 +565,7 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
             astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, q0, nq, Lmax, path, len, cost,
                          status, (uint32_t*)ctx->gslots.p, (uint32_t*)ctx->buckets.p, cap, (int32_t*)ctx->qstats.p,
                          getenv("SC_ASTAR_DEBUG") ? (int32_t*)ctx->qstats.p + Q : nullptr, redo,
-                         etag, gmask};
+                         tw, etag, gmask};
             int tk = sc_time_begin(ctx, SC_K_ASTAR);
             hipLaunchKernelGGL(astar_kernel, dim3(nq), dim3(64), 0, ctx->stream, a);
             sc_time_end(ctx, tk);
@@ -602,7 +627,7 @@ extern "C" int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int
     r = astar_run(ctx, d2, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status);
     if (r != SC_OK) return r;
     hipLaunchKernelGGL(gfield_untag_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)ctx->gslots.p, cells, ctx->astar_last_tag, ctx->astar_last_mask, gfield);
+                       (const uint32_t*)ctx->gslots.p, W, H, (W + 3) >> 2, ctx->astar_last_tag, ctx->astar_last_mask, gfield);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
