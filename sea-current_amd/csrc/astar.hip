@@ -574,7 +574,8 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
         // Bucket-ring overflow is rare (cap is generous) but must be seen on the host to retry.
         std::vector<int32_t> st(Q);
         SC_HIP(ctx, hipMemcpyAsync(st.data(), status, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        r = sc_stream_wait(ctx);   // milliseconds: sleep, do not spin
+        if (r != SC_OK) return r;
         bool any = false;
         for (int q = 0; q < Q; ++q) any |= st[q] == Q_OVERFLOW;
         if (!any) return SC_OK;

@@ -44,6 +44,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
     free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
     for (auto& s : ctx->staging) free_scratch(&s);
@@ -64,10 +65,17 @@ extern "C" int sc_ctx_use_own_stream(sc_ctx* ctx) {
     return SC_OK;
 }
 
+int sc_stream_wait(sc_ctx* ctx) {
+    if (!ctx->wait_ev) SC_HIP(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
+    SC_HIP(ctx, hipEventRecord(ctx->wait_ev, ctx->stream));
+    SC_HIP(ctx, hipEventSynchronize(ctx->wait_ev));
+    return SC_OK;
+}
+
 extern "C" int sc_ctx_synchronize(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return SC_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    return sc_stream_wait(ctx);
 }
 
 int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {

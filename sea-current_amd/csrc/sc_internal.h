@@ -18,6 +18,7 @@ struct sc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t wait_ev = nullptr;   // blocking-sync event: host waits sleep instead of spinning (one host thread per context in flight)
     char err[256] = {0};
     // timing
     int timing = 0;
@@ -65,6 +66,9 @@ int sc_time_chain(sc_ctx* ctx, int token, int kid);
 // kernels' host launchers (defined in the respective .hip files)
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
 int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, uint8_t* moves);
+
+// wait for everything enqueued on the context's stream without burning a host core
+int sc_stream_wait(sc_ctx* ctx);
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void wave_lds_sync() {
