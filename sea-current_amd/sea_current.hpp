@@ -26,8 +26,9 @@
 // Also mirrored from the "next" rows: bezier_spline::from_path, ::arclength, ::resample,
 // ::curvature, ::angular_velocity -- with these the reference's whole example pipeline (examples/zmq_test.cpp:66-93)
 // runs through this header.  bezier_spline::pts is a std::vector<Vector2f> (the reference: Matrix<float,Dynamic,2>).
-// Not mirrored: the 10001-point display sampling of from_path, FMT* sampling helpers (halton, sample_free, near),
-// JSON/ZMQ I/O.
+// The planner's sampling helpers keep their signatures as host functions (halton, sample_free, near, point_set,
+// x_state / y_state); fast_marching_trees itself plans on the grid.  Not mirrored: the 10001-point display sampling of
+// from_path, JSON/ZMQ I/O.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -38,11 +39,13 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <optional>
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_set>
 #include <vector>
 
 #include "../include/sea_current_hip.h"
@@ -288,11 +291,60 @@ public:
 };
 
 // ---- planning_space (sea_current.hpp:298-319, 1272-1407) --------------------------------------------
+// ---- sampling helpers of the reference's planner (sea_current.hpp:90-132, 287-296) ----------------
+// State of the incremental Halton generator: the last fraction was f / i.
+struct halton_state {
+    int f = 0;
+    int i = 0;
+    halton_state(int f, int i) : f(f), i(i) {}
+    halton_state() : f(0), i(0) {}
+};
+
+// next n numbers of the base-b Halton sequence (1/b, 2/b, ..., 1/b^2, ...), continuing from `state` (same signature and
+// float results as :100-132: integer numerator / denominator, one float division per number)
+inline std::vector<float> halton(const int b, const int n, halton_state& state) {
+    std::vector<float> nums(n);
+    int num = 0, den = 1;
+    if (state.i != 0 && state.f != 0) { den = state.i; num = state.f; }
+    for (int j = 0; j < n; ++j) {
+        const int gap = den - num;
+        if (gap == 1) {              // the current power of b is used up: start the next one
+            num = 1;
+            den *= b;
+        } else {
+            int y = den / b;
+            while (gap <= y) y /= b;
+            num = (b + 1) * y - gap;
+        }
+        nums[j] = static_cast<float>(num) / den;
+    }
+    state.f = num;
+    state.i = den;
+    return nums;
+}
+
+// hash of a point by the bit patterns of its coordinates (:287-295)
+struct hash_vector2f {
+    size_t operator()(const Vector2f v) const {
+        const float fa = v.x(), fb = v.y();
+        int32_t a, b;
+        std::memcpy(&a, &fa, 4);
+        std::memcpy(&b, &fb, 4);
+        return std::hash<int32_t>()(a) ^ std::hash<int32_t>()(b);
+    }
+};
+struct equal_vector2f {
+    bool operator()(const Vector2f& a, const Vector2f& b) const { return a.x() == b.x() && a.y() == b.y(); }
+};
+using point_set = std::unordered_set<Vector2f, hash_vector2f, equal_vector2f>;
+
 class planning_space {
 public:
     std::vector<obstacle> obstacles;
     std::vector<std::function<bool(Vector2f)>> free_space_allocations;
     bounding_rect bound_rect;
+    halton_state x_state;       // Halton state of sample_free (bases 2 and 3), advanced by every call (:317-318)
+    halton_state y_state;
     int grid_cells = 256;       // cells along the longer side of bound_rect (new knob)
     float clearance = 0.0f;     // required obstacle clearance in world units (new knob)
 
@@ -309,6 +361,52 @@ public:
         return false;
     }
     bool is_free(const Vector2f& p) { return !std::get<0>(is_obstacle(p)) && is_free_space_allocated(p); }
+    // n free points of the bounding rectangle from the Halton sequence, (0,0) included (:1294-1313; no stdout print).
+    // The reference never returns when nothing can be free (no free-space allocation); this throws instead.
+    point_set sample_free(const int n) {
+        if (free_space_allocations.empty() && n > 1)
+            throw std::logic_error("planning_space::sample_free: no free-space allocation, no point can be free");
+        point_set pts = {Vector2f(0, 0)};
+        pts.reserve(n);
+        size_t tested = 0;
+        while ((size_t)n > pts.size()) {
+            const int want = n - (int)pts.size();
+            const std::vector<float> xs = halton(2, want, x_state), ys = halton(3, want, y_state);
+            for (int i = 0; i < want; ++i) {
+                const Vector2f test((bound_rect.x_max - bound_rect.x_min) * xs[i] + bound_rect.x_min,
+                                    (bound_rect.y_max - bound_rect.y_min) * ys[i] + bound_rect.y_min);
+                if (is_free(test)) pts.insert(test);
+            }
+            tested += (size_t)want;
+            if (tested > 1000 * (size_t)n + 100000 && pts.size() <= 1)
+                throw std::runtime_error("planning_space::sample_free: no free point found");
+        }
+        return pts;
+    }
+    // points of `nodes` within `dist` of b, b itself excluded.  The reference compares the (unsquared) distance with
+    // dist squared (:1331); kept, so that radii mean the same thing in both libraries.
+    point_set near(const Vector2f b, const point_set& nodes, const float dist) const {
+        point_set out;
+        out.reserve(nodes.size());
+        for (const auto& a : nodes)
+            if (pt_dist(a, b) <= std::pow(dist, 2) && !(a.x() == b.x() && a.y() == b.y())) out.insert(a);
+        return out;
+    }
+    // both points within epsilon of (the supporting lines of) one obstacle's edges (:444-463; the reference tests `a`
+    // twice, so does this)
+    bool is_same_obstacle_fuzzy(const Vector2f& a, const Vector2f& b, const float epsilon) {
+        (void)b;
+        for (const auto& ob : obstacles) {
+            bool tag = false;
+            for (const auto& [p1, p2] : ob.lines) {
+                const Vector2f e = p2 - p1;
+                const float len = e.norm();
+                if (len > 0 && std::fabs((p2.x() - p1.x()) * (p1.y() - a.y()) - (p1.x() - a.x()) * (p2.y() - p1.y())) / len < epsilon) tag = true;
+            }
+            if (tag) return true;
+        }
+        return false;
+    }
     // length of segment ab, FLT_MAX if it crosses any obstacle edge (:1315-1326)
     float cost(const Vector2f a, const Vector2f b) const {
         for (const auto& ob : obstacles)

@@ -41,6 +41,30 @@ int main() {
     CHECK(batch.size() == 2 && batch[0].has_value() && batch[1].has_value());
     CHECK(batch[0]->size() == path->size());
 
+    // --- sampling helpers keep their signatures (sea_current.hpp:100-132, 1294-1337) ---
+    {
+        halton_state st2, st3;
+        const std::vector<float> h2 = halton(2, 7, st2), h3 = halton(3, 4, st3);
+        const float e2[7] = {0.5f, 0.25f, 0.75f, 0.125f, 0.625f, 0.375f, 0.875f}, e3[4] = {1.0f / 3, 2.0f / 3, 1.0f / 9, 4.0f / 9};
+        for (int i = 0; i < 7; ++i) CHECK(h2[i] == e2[i]);
+        for (int i = 0; i < 4; ++i) CHECK(h3[i] == e3[i]);
+        const std::vector<float> more = halton(2, 2, st2);           // continues where the state left off
+        CHECK(more[0] == 0.0625f && more[1] == 0.5625f);
+        planning_space sp(br);
+        sp.obstacles = space.obstacles;
+        sp.free_space_allocations.push_back([](Vector2f) { return true; });
+        const point_set pts = sp.sample_free(64);
+        CHECK(pts.size() == 64 && pts.count(Vector2f(0, 0)) == 1);
+        for (const auto& p : pts) CHECK(p.x() >= -1 && p.x() <= 1 && p.y() >= -1 && p.y() <= 1 && (!std::get<0>(sp.is_obstacle(p)) || (p.x() == 0 && p.y() == 0)));
+        const point_set nb = sp.near(Vector2f(0, 0), pts, 0.7f);     // radius: distance <= 0.7^2
+        for (const auto& p : nb) CHECK(p.norm() <= 0.49f + 1e-6f && !(p.x() == 0 && p.y() == 0));
+        size_t cnt = 0;
+        for (const auto& p : pts) cnt += (p.norm() <= 0.49f && !(p.x() == 0 && p.y() == 0));
+        CHECK(cnt == nb.size());
+        bool threw = false;
+        try { planning_space none(br); none.sample_free(8); } catch (const std::logic_error&) { threw = true; }
+        CHECK(threw);
+    }
     // --- smoothing: examples/zmq_test.cpp:61-68 on the recorded request (0,0),(10,0),(10,10) ---
     {
         const bounding_rect br2 = {10, -10, 10, -10};
