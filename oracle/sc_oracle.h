@@ -50,6 +50,9 @@ void sco_edt_exact(const uint8_t* occ, int W, int H, int32_t* d2);
  *   parent(c) = smallest d such that n = c - (dx_d,dy_d) is traversable, the
  *   move n->c is legal and g[n] + w_d == g[c].
  *   path = start..goal obtained by following parent() from goal.
+ * Parity contract of the HIP kernel: status, cost, len, path, and g on E are
+ * bit-exact; outside E the kernel's successor pruning leaves values >= the g
+ * defined above (tests/test_gpu_astar.py::test_astar_gfield_bit_exact).
  */
 #define SCO_G_INF 0xFFFFFFFFu
 enum { SCO_OK = 0, SCO_NO_PATH = 1, SCO_BAD_ENDPOINT = 2, SCO_PATH_TRUNCATED = 3 };

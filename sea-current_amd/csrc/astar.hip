@@ -118,15 +118,38 @@ __device__ __forceinline__ void masked_atomic_min2(uint32_t* const (&ad)[2], con
                  : "vcc", "memory");
 }
 
-// Relaxations that can never improve anything are pruned at insertion time.  If c was reached from
-// its parent p by move d, a neighbour n of c that p can also reach by ONE legal move e was already
-// relaxed by p at a cost <= the cost through c (and n == p trivially).  ALWAYS[d]: the three
-// neighbours for which p's move is legal whenever c's is (reverse direction and the two cells that
-// touch p).  For straight d two more (the cells diagonal to p) depend on p's own move mask.
+// Relaxations that can never give a node its optimal g are pruned at insertion time (the neighbour pruning of jump
+// point search, without the jumps).  c was reached from its parent p by move d; the relaxation c -> n is dropped when
+// a route p -> m -> n exists that is legal whenever c -> n is, costs no more, and -- on a tie -- starts with the
+// diagonal move (so the justifications cannot be circular):
+//   ALWAYS[d]  n == p, the two cells that touch p (m == n: one move from p), and for diagonal d the two cells two
+//              straight steps from p (p -> m -> n costs 20 < 14 + 14; the diagonal being legal means m is free);
+//   straight d, per side: if p's diagonal move e on that side is legal, the cell beside c (one move e from p, 14 < 20)
+//              and the cell diagonally ahead of c (p -e-> m -d-> n, 14 + 10 on both routes).
+// Every node of E still receives g*: the cheaper-or-equal route runs through nodes whose f does not exceed f(n).  The
+// values left in cells OUTSIDE E (never expanded) are upper bounds that depend on which relaxations were dropped.
 __device__ __forceinline__ uint32_t prune_always(int d) {
     // d: 0 E, 1 W, 2 S(+y), 3 N, 4 SE, 5 SW, 6 NE, 7 NW
-    const unsigned long long T = 0x1526498A34C851A2ull;  // bytes: A2 51 C8 34 8A 49 26 15
+    const unsigned long long T = 0x75B6D9EA34C851A2ull;  // bytes: A2 51 C8 34 EA D9 B6 75
     return (uint32_t)(T >> (8 * d)) & 0xFFu;
+}
+
+// HBM bucket entry: y << 19 | side flags << 16 | arrival move << 13 | x  (x, y < 8192).  The side flags keep the
+// parent's two diagonal-move bits that the conditional pruning of a straight arrival needs (see above).
+__device__ __forceinline__ uint32_t entry_pack(int x, int y, int d, uint32_t pmv) {
+    const int e0 = (int)((0x6476u >> (4 * (d & 3))) & 7u), e1 = (int)((0x7554u >> (4 * (d & 3))) & 7u);
+    const uint32_t side = d < 4 ? (((pmv >> e0) & 1u) | (((pmv >> e1) & 1u) << 1)) : 0u;
+    return (uint32_t)y << 19 | side << 16 | (uint32_t)d << 13 | (uint32_t)x;
+}
+// moves of a popped entry that are pruned: ALWAYS[d] plus, for straight d, the two cells per side flag
+__device__ __forceinline__ uint32_t entry_prune(uint32_t e) {
+    const int d = (int)((e >> 13) & 7u);
+    uint32_t prune = prune_always(d);
+    const int k0 = d < 2 ? 3 : 0, k1 = d < 2 ? 2 : 1;
+    const int e0 = (int)((0x6476u >> (4 * (d & 3))) & 7u), e1 = (int)((0x7554u >> (4 * (d & 3))) & 7u);
+    if ((e >> 16) & 1u) prune |= (1u << k0) | (1u << e0);
+    if ((e >> 17) & 1u) prune |= (1u << k1) | (1u << e1);
+    return prune;
 }
 
 __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
@@ -263,7 +286,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         valid[k] = false; cx[k] = cy[k] = 0; gv[k] = 0; mm[k] = 0; de[k] = 0;
                         if (8 * k + sub < n) {
                             const uint32_t e = bq[(hd + 8 * k + sub) & capm];
-                            cx[k] = e & 0x1FFF; de[k] = (e >> 13) & 7; cy[k] = e >> 16;
+                            cx[k] = e & 0x1FFF; de[k] = e; cy[k] = e >> 19;
                             const int c = cy[k] * W + cx[k];
                             gv[k] = g_load(&g[gix(cx[k], cy[k], tw)]);
                             mm[k] = a.moves[c];
@@ -275,7 +298,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         gc[k] = gv[k] & gmask;
                         // stale unless it still carries this launch's tag and the g that put it in this bucket
                         valid[k] = valid[k] && (gv[k] & ~gmask) == etag && (int)(gc[k] + octile(cx[k], cy[k], gx, gy)) == fcur;
-                        mv[k] = mm[k] & ~prune_always((int)de[k]);
+                        mv[k] = mm[k] & ~entry_prune(de[k]);
                     }
                     if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
@@ -325,7 +348,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     const int df = (int)ng + octile(nx, ny, gx, gy) - fcur;  // in {0,6,8,14,20,28}
                     // moves worth trying from the successor
                     uint32_t prune = p_always;
-                    if (p_cond) prune |= (((mv[k] >> ce0) & 1u) << ck0) | (((mv[k] >> ce1) & 1u) << ck1);
+                    if (p_cond) prune |= (((mv[k] >> ce0) & 1u) << ck0) | (((mv[k] >> ce1) & 1u) << ck1) | (mv[k] & ((1u << ce0) | (1u << ce1)));
                     const uint32_t smv = nmv[k] & ~prune;
                     // same-f successors: consecutive slots of the LDS ring by ballot rank
                     const bool same = imp && df == 0;
@@ -347,7 +370,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         const int bb = (fcur + df) & 31;
                         const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if (pos - HEAD(bb) >= cap) ovf = true;
-                        else bk[(size_t)bb * cap + (pos & capm)] = (uint32_t)(ny << 16 | d << 13 | nx);
+                        else bk[(size_t)bb * cap + (pos & capm)] = entry_pack(nx, ny, d, mv[k]);
                     }
                 }
 #ifdef ASTAR_STAMPS
@@ -374,14 +397,14 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     uint32_t gv = 0, mm = 0, de = 0;
                     if (lane < n) {
                         const uint32_t e = bq[(hd + lane) & capm];
-                        cx = e & 0x1FFF; de = (e >> 13) & 7; cy = e >> 16;
+                        cx = e & 0x1FFF; de = e; cy = e >> 19;
                         gv = g_load(&g[gix(cx, cy, tw)]);
                         mm = a.moves[cy * W + cx];
                         valid = true;
                     }
                     gc = gv & gmask;
                     valid = valid && (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
-                    mv = mm & ~prune_always((int)de);
+                    mv = mm & ~entry_prune(de);
                     if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 if (!valid) mv = 0;
@@ -412,7 +435,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     uint32_t prune = prune_always(dd);
                     if (dd < 4) {
                         const int k0 = dd < 2 ? 3 : 0, e0 = (0x6476 >> (4 * dd)) & 7, k1 = dd < 2 ? 2 : 1, e1 = (0x7554 >> (4 * dd)) & 7;
-                        prune |= (((mv >> e0) & 1u) << k0) | (((mv >> e1) & 1u) << k1);
+                        prune |= (((mv >> e0) & 1u) << k0) | (((mv >> e1) & 1u) << k1) | (mv & ((1u << e0) | (1u << e1)));
                     }
                     const uint32_t smv = nmv[dd] & ~prune;
                     // same-f successors: consecutive slots of the LDS ring by ballot rank
@@ -435,7 +458,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         const int bb = (fcur + df) & 31;
                         const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if (pos - HEAD(bb) >= cap) ovf = true;
-                        else bk[(size_t)bb * cap + (pos & capm)] = (uint32_t)(ny << 16 | dd << 13 | nx);
+                        else bk[(size_t)bb * cap + (pos & capm)] = entry_pack(nx, ny, dd, mv);
                     }
                 }
             };
