@@ -62,7 +62,8 @@ typedef enum {
     SC_K_ARCLENGTH = 7,   /* GL-32 arclength tables */
     SC_K_RESAMPLE = 8,    /* resample: nudge + split, Chebyshev fit + evaluation */
     SC_K_OCC = 9,         /* occupancy grid from a rectangle list (dynamic-obstacle frames) */
-    SC_K_COUNT = 10
+    SC_K_NEAREST = 10,    /* nearest obstacle cell from d2 */
+    SC_K_COUNT = 11
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -102,6 +103,11 @@ int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes);
  * mathematically (oracle/sc_oracle.h). */
 int sc_edt_u8_i32(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
 int sc_edt_u8_i32_host(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
+
+/* Optional second output of the EDT: nearest[b][y][x] = linear index (y' * W + x') of the occupied cell
+ * nearest to (x, y) in grid b, the smallest index among equidistant ones, -1 when the grid has no obstacle.  Needs
+ * the d2 of sc_edt_u8_i32 for the same occ.  9 B/cell with d2 instead of 5.  Device pointers. */
+int sc_edt_nearest_i32(sc_ctx* ctx, const uint8_t* occ, const int32_t* d2, int W, int H, int batch, int32_t* nearest);
 
 /* Occupancy grid of a frame of the dynamic-obstacle replan loop (BASELINE.json configs[4]): occ = base (or all free
  * when base is NULL; base == occ paints in place) with R cell rectangles (x0, y0, x1, y1; x1/y1 exclusive; clipped)

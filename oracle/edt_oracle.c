@@ -87,3 +87,47 @@ void sco_edt_exact(const uint8_t* occ, int W, int H, int32_t* d2) {
     }
     free(s); free(t); free(G);
 }
+
+/* nearest[c] = linear index of the occupied cell closest to c; among equidistant ones the smallest index; -1 when the
+ * grid is empty.  Definition by exhaustive search (small grids). */
+void sco_edt_nearest_brute(const uint8_t* occ, int W, int H, int32_t* nearest) {
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int64_t best = INT64_MAX;
+            int32_t arg = -1;
+            for (int yy = 0; yy < H; ++yy)
+                for (int xx = 0; xx < W; ++xx)
+                    if (occ[(size_t)yy * W + xx]) {
+                        const int64_t dx = x - xx, dy = y - yy, d = dx * dx + dy * dy;
+                        if (d < best) { best = d; arg = yy * W + xx; }   /* scan order = index order: first hit is the smallest */
+                    }
+            nearest[(size_t)y * W + x] = arg;
+        }
+}
+
+/* Same result from the exact d2: the nearest cell lies on the circle dx^2 + dy^2 = d2 around c, so only the integer
+ * points of that circle are tested (O(sqrt d2) per cell; any grid size). */
+void sco_edt_nearest(const uint8_t* occ, const int32_t* d2, int W, int H, int32_t* nearest) {
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int32_t D = d2[(size_t)y * W + x];
+            int32_t arg = -1;
+            if (D != SCO_EDT_INF) {
+                int64_t best = INT64_MAX;
+                for (int64_t dx = 0; dx * dx <= D; ++dx) {
+                    const int64_t rem = D - dx * dx;
+                    int64_t dy = 0;
+                    while ((dy + 1) * (dy + 1) <= rem) ++dy;
+                    if (dy * dy != rem) continue;
+                    for (int sx = -1; sx <= 1; sx += 2)
+                        for (int sy = -1; sy <= 1; sy += 2) {
+                            const int64_t xx = x + sx * dx, yy = y + sy * dy;
+                            if (xx < 0 || yy < 0 || xx >= W || yy >= H || !occ[(size_t)yy * W + xx]) continue;
+                            if (yy * W + xx < best) best = yy * W + xx;
+                        }
+                }
+                arg = (int32_t)best;
+            }
+            nearest[(size_t)y * W + x] = arg;
+        }
+}

@@ -49,6 +49,19 @@ def edt(occ, exact=True):
     return d2
 
 
+def edt_nearest(occ, d2=None):
+    """Index of the nearest occupied cell per cell (ties: smallest index; -1: empty grid).  d2=None: brute force."""
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    H, W = occ.shape
+    out = np.empty((H, W), dtype=np.int32)
+    if d2 is None:
+        lib().sco_edt_nearest_brute(_p(occ, C.c_uint8), C.c_int(W), C.c_int(H), _p(out, C.c_int32))
+    else:
+        d2 = np.ascontiguousarray(d2, dtype=np.int32)
+        lib().sco_edt_nearest(_p(occ, C.c_uint8), _p(d2, C.c_int32), C.c_int(W), C.c_int(H), _p(out, C.c_int32))
+    return out
+
+
 def moves(d2, r2=0):
     d2 = np.ascontiguousarray(d2, dtype=np.int32)
     H, W = d2.shape

@@ -36,6 +36,11 @@ void sco_edt_brute(const uint8_t* occ, int W, int H, int32_t* d2);
  * of parabolas, all-integer comparisons).  O(W*H). */
 void sco_edt_exact(const uint8_t* occ, int W, int H, int32_t* d2);
 
+/* nearest[y*W+x] = linear index of the nearest occupied cell (smallest index among equidistant ones), -1 if the grid is
+ * empty.  _brute is the definition; sco_edt_nearest walks the integer points of the circle of radius^2 d2. */
+void sco_edt_nearest_brute(const uint8_t* occ, int W, int H, int32_t* nearest);
+void sco_edt_nearest(const uint8_t* occ, const int32_t* d2, int W, int H, int32_t* nearest);
+
 /* ---- A* --------------------------------------------------------------- */
 /* Move d in 0..7: dx = {1,-1,0,0,1,-1,1,-1}, dy = {0,0,1,-1,1,1,-1,-1};
  * cost 10 for d<4, 14 for d>=4.  Cell c traversable iff d2[c] >= max(r2,1).

@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC = range(10)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST = range(11)
 
 _lib = None
 
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_sample_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
     "sc_toppra_sample_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+    "sc_edt_nearest_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sc_occ_from_rects": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
@@ -248,6 +249,15 @@ class Context:
                                                 _ptr(out["acc"]), _ptr(out["time"]), _ptr(out["length"])),
                  "sc_toppra_sample_batch")
         return out
+
+    def edt_nearest(self, occ, d2):
+        """occ uint8 [B,H,W] or [H,W] and its d2 (GPU) -> int32 index of the nearest occupied cell per cell (-1: none)."""
+        import torch
+        o3 = occ if occ.dim() == 3 else occ[None]
+        B, H, W = o3.shape
+        out = torch.empty((B, H, W), dtype=torch.int32, device=occ.device)
+        self._ck(self._l.sc_edt_nearest_i32(self._h, _ptr(o3), _ptr(d2), W, H, B, _ptr(out)), "sc_edt_nearest_i32")
+        return out if occ.dim() == 3 else out[0]
 
     def occ_from_rects(self, rects, W, H, base=None, free_border=True, out=None):
         """rects int32 [R,4] (x0,y0,x1,y1 exclusive; GPU) painted over `base` uint8 [H,W] (or an empty grid) -> occ uint8 [H,W]."""

@@ -91,3 +91,28 @@ def test_edt_4096_properties(ctx):
         y, x = rng.integers(0, 4096, 2)
         m = (np.abs(ys - y) <= 64) & (np.abs(xs - x) <= 64)
         assert d2[y, x] == ((ys[m] - y) ** 2 + (xs[m] - x) ** 2).min()
+
+
+def test_edt_nearest_matches_oracle(ctx, oracle):
+    import torch
+    from sea_current_amd import synth
+    grids = [synth.salt_grid(97, 61, 0.05, seed=4), synth.salt_grid(64, 64, 0.3, seed=5), synth.block_grid(200, 150, 0.2, seed=6, smin=3, smax=30),
+             np.zeros((33, 47), np.uint8)]
+    grids[3][10, 10] = 1
+    for occ in grids:
+        o = torch.from_numpy(occ).cuda()
+        d2 = ctx.edt(o)
+        nn = ctx.edt_nearest(o, d2)
+        torch.cuda.synchronize()
+        assert np.array_equal(nn.cpu().numpy(), oracle.edt_nearest(occ, oracle.edt(occ)))
+    occ = synth.salt_grid(48, 40, 0.1, seed=7)
+    nn = ctx.edt_nearest(torch.from_numpy(occ).cuda(), ctx.edt(torch.from_numpy(occ).cuda()))
+    assert np.array_equal(nn.cpu().numpy(), oracle.edt_nearest(occ))            # against the exhaustive definition
+    empty = torch.zeros((2, 16, 16), dtype=torch.uint8, device="cuda")
+    assert (ctx.edt_nearest(empty, ctx.edt(empty)) == -1).all()
+    big = synth.salt_grid(1024, 1024, 0.2)
+    ob = torch.from_numpy(np.stack([big, synth.block_grid(1024, 1024, 0.2)])).cuda()
+    d2b = ctx.edt(ob)
+    nb = ctx.edt_nearest(ob, d2b).cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(nb[k], oracle.edt_nearest(ob[k].cpu().numpy(), d2b[k].cpu().numpy()))

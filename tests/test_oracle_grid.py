@@ -182,3 +182,19 @@ def test_batch_equals_single_and_threads(oracle):
     for q in range(24):
         r = oracle.astar(d2, s[q], g[q])
         assert r["cost"] == b1["cost"][q] and np.array_equal(r["path"], b1["path"][q, :r["len"]])
+
+
+def test_edt_nearest_oracle(oracle):
+    """nearest-cell oracle: the circle walk equals the exhaustive definition, ties go to the smallest index."""
+    from sea_current_amd import synth
+    for W, H, p, seed in [(23, 17, 0.1, 1), (40, 31, 0.02, 2), (16, 16, 0.5, 3)]:
+        occ = synth.salt_grid(W, H, p, seed=seed)
+        d2 = oracle.edt(occ)
+        nb = oracle.edt_nearest(occ)
+        assert np.array_equal(oracle.edt_nearest(occ, d2), nb)
+        ys, xs = np.divmod(nb, W)
+        yy, xx = np.mgrid[0:H, 0:W]
+        assert np.array_equal((yy - ys) ** 2 + (xx - xs) ** 2, d2) and occ.ravel()[nb.ravel()].all()
+    occ = np.zeros((5, 7), np.uint8); occ[2, 1] = occ[2, 5] = 1      # (3,2) is equidistant: smallest index wins
+    assert oracle.edt_nearest(occ)[2, 3] == 2 * 7 + 1
+    assert (oracle.edt_nearest(np.zeros((4, 4), np.uint8)) == -1).all()
