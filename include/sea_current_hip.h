@@ -63,7 +63,8 @@ typedef enum {
     SC_K_RESAMPLE = 8,    /* resample: nudge + split, Chebyshev fit + evaluation */
     SC_K_OCC = 9,         /* occupancy grid from a rectangle list (dynamic-obstacle frames) */
     SC_K_NEAREST = 10,    /* nearest obstacle cell from d2 */
-    SC_K_COUNT = 11
+    SC_K_FMT = 11,        /* FMT* over Halton samples (the reference's own planner), one wavefront per query */
+    SC_K_COUNT = 12
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -224,6 +225,21 @@ int sc_bezier_resample_batch(sc_ctx* ctx, const float* ctrl, const float* cum, c
 int sc_bezier_resample_batch_host(sc_ctx* ctx, const float* ctrl, const float* cum, const float* arclength, const int32_t* seg_off,
                                   int B, int S, int nsub, float* profile_pos, const int32_t* prof_off, int nudge, float* pts,
                                   float* tpar, int32_t* seg, float* curvature, int32_t* status);
+
+/* ---- the reference's own planner, batched -----------------------------------------------
+ * planning_space::fast_marching_trees (sea_current.hpp:1339-1407) with near (:1328-1337), cost (:1315-1326) and
+ * intersects (:142-178): FMT* from starts[q] to goals[q] (float [Q][2]) over n shared free samples (float [n][2], e.g.
+ * from sample_free :1294-1313; the reference draws them inside the call) with connection radius rn (the reference
+ * compares distances with rn squared; so does this) around obstacle edges lines (float [E][4]).  path float
+ * [Q][Lmax][2] start..goal, len [Q], cost float [Q] (cost-to-come of the goal), status [Q] (SC_Q_OK / SC_Q_NO_PATH /
+ * SC_Q_TRUNCATED).  Equal costs are resolved towards the lowest node index (samples in order, then goal, then start);
+ * the reference resolves them by unordered_set iteration order. */
+#define SC_FMT_MAX_SAMPLES 2046
+#define SC_FMT_MAX_EDGES 512
+int sc_fmt_star_batch(sc_ctx* ctx, const float* samples, int n, const float* starts, const float* goals, int Q, float rn,
+                      const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status);
+int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, const float* starts, const float* goals, int Q, float rn,
+                           const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status);
 
 #ifdef __cplusplus
 }

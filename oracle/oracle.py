@@ -183,3 +183,40 @@ def bezier_resample(ctrl, cum, arclength, profile_pos, nudge=True):
     st = f(_p(ctrl, C.c_float), C.c_int(nseg), C.c_int(m - 1), _p(cum, C.c_float), C.c_float(float(arclength)), _p(pp, C.c_float),
            C.c_int(n), C.c_int(1 if nudge else 0), _p(pts, C.c_float), _p(tpar, C.c_float), _p(seg, C.c_int32), _p(curv, C.c_float))
     return dict(status=st, pos=pp, pts=pts, t=tpar, seg=seg, curvature=curv)
+
+
+def halton(b, n, state=(0, 0)):
+    """next n base-b Halton numbers from state (f, i) -> (float32 [n], new state)."""
+    f, i = C.c_int(state[0]), C.c_int(state[1])
+    out = np.zeros(n, np.float32)
+    lib().sco_halton(C.c_int(b), C.c_int(n), C.byref(f), C.byref(i), _p(out, C.c_float))
+    return out, (f.value, i.value)
+
+
+def sample_free(n, rect, lines, obs_off, hstate=(0, 0, 0, 0)):
+    """-> (pts float32 [n,2], new hstate); rect = (x_min, x_max, y_min, y_max)."""
+    rect = np.asarray(rect, np.float32)
+    lines = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    obs_off = np.ascontiguousarray(obs_off, np.int32)
+    hs = np.array(hstate, np.int32)
+    pts = np.zeros((n, 2), np.float32)
+    f = lib().sco_sample_free
+    f.restype = C.c_int
+    st = f(C.c_int(n), _p(rect, C.c_float), _p(lines, C.c_float), _p(obs_off, C.c_int32), C.c_int(obs_off.shape[0] - 1), _p(hs, C.c_int32),
+           _p(pts, C.c_float))
+    if st:
+        raise RuntimeError("sample_free: no free point")
+    return pts, tuple(int(v) for v in hs)
+
+
+def fmt_star(samples, start, goal, rn, lines, Lmax=256):
+    samples = np.ascontiguousarray(samples, np.float32)
+    lines = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    path = np.zeros((Lmax, 2), np.float32)
+    ln, cost = C.c_int32(0), C.c_float(0)
+    f = lib().sco_fmt_star
+    f.restype = C.c_int
+    st = f(_p(samples, C.c_float), C.c_int(samples.shape[0]), C.c_float(start[0]), C.c_float(start[1]), C.c_float(goal[0]),
+           C.c_float(goal[1]), C.c_float(rn), _p(lines, C.c_float), C.c_int(lines.shape[0]), C.c_int(Lmax), _p(path, C.c_float),
+           C.byref(ln), C.byref(cost))
+    return dict(status=st, len=ln.value, cost=cost.value, path=path[:min(ln.value, Lmax)])

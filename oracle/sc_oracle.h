@@ -119,6 +119,17 @@ double sco_bezier_arclength(const float* ctrl, int nseg, int nsub, double* cum);
 int sco_bezier_resample(const float* ctrl, int nseg, int nsub, const float* cum, float arclength, float* profile_pos, int n,
                         int nudge, float* pts, float* tpar, int32_t* seg, float* curv);
 
+/* ---- the reference's own planner: FMT* over Halton samples --------------------------------
+ * Restates sea_current.hpp:100-132 (halton), :1294-1313 (sample_free), :1328-1337 (near), :1315-1326 + :142-178 (cost),
+ * :1339-1407 (fast_marching_trees); see fmt_oracle.c for the tie-break and free-space conventions.  PARITY UNPINNED.
+ * lines [E][4] obstacle edges, obs_off [nobs+1] edge ranges per obstacle, rect = (x_min, x_max, y_min, y_max),
+ * hstate = (f2, i2, f3, i3) Halton states of bases 2 and 3 (advanced). */
+void sco_halton(int b, int n, int* f_state, int* i_state, float* out);
+int sco_point_in_obstacles(float px, float py, const float* lines, const int* obs_off, int nobs);
+int sco_sample_free(int n, const float* rect, const float* lines, const int* obs_off, int nobs, int* hstate, float* pts);
+int sco_fmt_star(const float* samples, int n, float sx, float sy, float gx, float gy, float rn, const float* lines, int E, int Lmax,
+                 float* path, int32_t* len, float* cost_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,3 +362,28 @@ extern "C" int sc_bezier_eval_batch_host(sc_ctx* ctx, const float* ctrl, int S, 
     SC_HIP(ctx, hipMemcpyAsync(out, b + cb + 2 * mb, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
     return sc_ctx_synchronize(ctx);
 }
+
+extern "C" int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, const float* starts, const float* goals, int Q, float rn,
+                                      const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status) {
+    if (!ctx || !samples || !starts || !goals || !path || !len || !cost || !status || n < 0 || Q < 0 || E < 0 || Lmax <= 0) return SC_ERR_INVALID;
+    if (Q == 0) return SC_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_s = 0, o_st = o_s + al((size_t)(n > 0 ? n : 1) * 8), o_g = o_st + al((size_t)Q * 8), o_l = o_g + al((size_t)Q * 8),
+                 o_p = o_l + al((size_t)(E > 0 ? E : 1) * 16), o_len = o_p + al((size_t)Q * Lmax * 8), o_c = o_len + al((size_t)Q * 4),
+                 o_status = o_c + al((size_t)Q * 4), total = o_status + al((size_t)Q * 4);
+    STAGE(6, total);
+    char* b = (char*)ctx->staging[6].p;
+    if (n) SC_HIP(ctx, hipMemcpyAsync(b + o_s, samples, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_st, starts, (size_t)Q * 8, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_g, goals, (size_t)Q * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (E) SC_HIP(ctx, hipMemcpyAsync(b + o_l, lines, (size_t)E * 16, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_fmt_star_batch(ctx, (const float*)(b + o_s), n, (const float*)(b + o_st), (const float*)(b + o_g), Q, rn, (const float*)(b + o_l), E,
+                              Lmax, (float*)(b + o_p), (int32_t*)(b + o_len), (float*)(b + o_c), (int32_t*)(b + o_status));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(path, b + o_p, (size_t)Q * Lmax * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(len, b + o_len, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(cost, b + o_c, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(status, b + o_status, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}

@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST = range(11)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST, K_FMT = range(12)
 
 _lib = None
 
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_sample_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
     "sc_toppra_sample_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_d, _i] + [_vp] * 5),
+    "sc_fmt_star_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.c_float, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sc_fmt_star_batch_host": (_i, [_vp, _vp, _i, _vp, _vp, _i, C.c_float, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_edt_nearest_i32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sc_occ_from_rects": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
@@ -248,6 +250,20 @@ class Context:
                                                 _ptr(t), float(dt), max_len, _ptr(out["pos"]), _ptr(out["vel"]),
                                                 _ptr(out["acc"]), _ptr(out["time"]), _ptr(out["length"])),
                  "sc_toppra_sample_batch")
+        return out
+
+    def fmt_star(self, samples, starts, goals, rn, lines, Lmax=256):
+        """FMT* (the reference's planner) for Q queries over shared samples.  GPU float32 tensors: samples [n,2], starts / goals
+        [Q,2], lines [E,4] -> dict(path [Q,Lmax,2], len, cost, status)."""
+        import torch
+        Q = starts.shape[0]
+        dev = starts.device
+        out = dict(path=torch.zeros((Q, Lmax, 2), dtype=torch.float32, device=dev), len=torch.zeros(Q, dtype=torch.int32, device=dev),
+                   cost=torch.zeros(Q, dtype=torch.float32, device=dev), status=torch.zeros(Q, dtype=torch.int32, device=dev))
+        E = 0 if lines is None else lines.shape[0]
+        self._ck(self._l.sc_fmt_star_batch(self._h, _ptr(samples), samples.shape[0], _ptr(starts), _ptr(goals), Q, float(rn),
+                                           _ptr(lines) if E else None, E, Lmax, _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]),
+                                           _ptr(out["status"])), "sc_fmt_star_batch")
         return out
 
     def edt_nearest(self, occ, d2):

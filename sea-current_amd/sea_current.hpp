@@ -12,6 +12,7 @@
 //   planning_space::is_free            :1289-1292         same signature
 //   planning_space::cost               :1315-1326         same signature and FLT_MAX convention
 //   planning_space::fast_marching_trees:1339-1407         same signature; grid EDT + batched A* on the GPU
+//   (new) planning_space::fast_marching_trees_sampled      the reference's FMT* itself (Halton samples, radius), batched on the GPU
 //   bezier_spline::from_path / arclength :599-683,:767-896  same signatures, GPU tangents + GL-32 tables
 //   bezier_spline::resample            :898-1005          same signature; nudge, split, Chebyshev fit and evaluation on the GPU
 //   bezier_spline::curvature / angular_velocity :1017-1067  same signatures
@@ -428,6 +429,35 @@ public:
         (void)n; (void)rn;
         auto r = plan_batch({x_init}, {x_goal});
         return r[0];
+    }
+    // The reference's own algorithm (FMT* over n Halton samples with connection radius rn, :1339-1407) for a batch of
+    // queries, on the GPU (sc_fmt_star_batch): one sample set (drawn like the reference does inside the call, advancing
+    // x_state / y_state once) shared by all queries.  Needs a free-space allocation, like sample_free.
+    std::vector<std::optional<std::vector<Vector2f>>> fast_marching_trees_sampled(const std::vector<Vector2f>& starts,
+                                                                                  const std::vector<Vector2f>& goals, const int n,
+                                                                                  const float rn, gpu_context& ctx = default_context()) {
+        const point_set ps = sample_free(n);
+        std::vector<float> smp, lines, st, gl;
+        smp.push_back(0.f); smp.push_back(0.f);                     // (0,0) first, as the reference inserts it (:1297)
+        for (const auto& p : ps)
+            if (!(p.x() == 0.f && p.y() == 0.f)) { smp.push_back(p.x()); smp.push_back(p.y()); }
+        for (const auto& ob : obstacles)
+            for (const auto& [a, b] : ob.lines) { lines.push_back(a.x()); lines.push_back(a.y()); lines.push_back(b.x()); lines.push_back(b.y()); }
+        const int Q = (int)starts.size(), Lmax = (int)smp.size() / 2 + 2;
+        for (int q = 0; q < Q; ++q) { st.push_back(starts[q].x()); st.push_back(starts[q].y()); gl.push_back(goals[q].x()); gl.push_back(goals[q].y()); }
+        std::vector<float> path((size_t)Q * Lmax * 2), cost(Q);
+        std::vector<int32_t> len(Q), status(Q);
+        ctx.check(sc_fmt_star_batch_host(ctx.get(), smp.data(), (int)smp.size() / 2, st.data(), gl.data(), Q, rn, lines.empty() ? nullptr : lines.data(),
+                                         (int)lines.size() / 4, Lmax, path.data(), len.data(), cost.data(), status.data()),
+                  "sc_fmt_star_batch_host");
+        std::vector<std::optional<std::vector<Vector2f>>> out(Q);
+        for (int q = 0; q < Q; ++q) {
+            if (status[q] != SC_Q_OK) continue;
+            std::vector<Vector2f> wp;
+            for (int i = 0; i < len[q]; ++i) wp.push_back(Vector2f(path[((size_t)q * Lmax + i) * 2], path[((size_t)q * Lmax + i) * 2 + 1]));
+            out[q] = std::move(wp);
+        }
+        return out;
     }
     // batched form: one grid, one EDT, Q queries in one GPU launch
     std::vector<std::optional<std::vector<Vector2f>>> plan_batch(const std::vector<Vector2f>& starts, const std::vector<Vector2f>& goals,

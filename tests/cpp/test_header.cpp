@@ -65,6 +65,20 @@ int main() {
         try { planning_space none(br); none.sample_free(8); } catch (const std::logic_error&) { threw = true; }
         CHECK(threw);
     }
+    // --- the reference's own FMT* (n = 200, rn = 1: the call of examples/test.cpp:284), batched on the GPU ---
+    {
+        planning_space sp(br);
+        sp.obstacles = space.obstacles;
+        sp.free_space_allocations.push_back([](Vector2f) { return true; });
+        auto r = sp.fast_marching_trees_sampled({Vector2f(-0.5, 1), Vector2f(-0.9, -0.9)}, {Vector2f(1, -1), Vector2f(0.5, 0.5)}, 200, 1.0f);
+        CHECK(r.size() == 2 && r[0].has_value() && !r[1].has_value());       // second goal lies inside an obstacle
+        const auto& wp = *r[0];
+        CHECK(wp.size() >= 3 && wp.front() == Vector2f(-0.5, 1) && wp.back() == Vector2f(1, -1));
+        float total = 0;
+        for (size_t i = 0; i + 1 < wp.size(); ++i) { CHECK(sp.cost(wp[i], wp[i + 1]) < FLT_MAX); total += sp.cost(wp[i], wp[i + 1]); }
+        CHECK(total >= 2.5f && total < 3.75f);                               // straight-line distance 2.5
+        CHECK(sp.x_state.i != 0 && sp.y_state.i != 0);                       // the Halton states advanced (:317-318)
+    }
     // --- smoothing: examples/zmq_test.cpp:61-68 on the recorded request (0,0),(10,0),(10,10) ---
     {
         const bounding_rect br2 = {10, -10, 10, -10};
