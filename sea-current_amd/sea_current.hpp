@@ -29,7 +29,7 @@
 // runs through this header.  bezier_spline::pts is a std::vector<Vector2f> (the reference: Matrix<float,Dynamic,2>).
 // The planner's sampling helpers keep their signatures as host functions (halton, sample_free, near, point_set,
 // x_state / y_state); fast_marching_trees itself plans on the grid.  Not mirrored: the 10001-point display sampling of
-// from_path, JSON/ZMQ I/O.
+// from_path, the ZMQ transport.  The service's request text and JSON reply are parse_path_request / serialize_path_to_json.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -40,6 +40,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <optional>
@@ -705,6 +707,54 @@ velocity_profile gen_vel_prof(const VectorNd<N>& pos_end, const VectorNd<N>& pos
     }
     r.vel_lim = vel_lim;
     return std::move(gen_vel_prof_batch({r}, dt)[0]);
+}
+
+// ---- wire formats of the example service ---------------------------------------------------
+// Request text of examples/zmq_test.cpp:30-59: "acc_min acc_max vel_min vel_max" then one "x y" pair per waypoint.
+struct path_request {
+    float acc_min = 0, acc_max = 0, vel_min = 0, vel_max = 0;
+    std::vector<Vector2f> path;
+    float max_x = 0, max_y = 0;   // largest |x|, |y|: the service builds its bounding_rect from them (:61)
+};
+inline path_request parse_path_request(const std::string& req) {
+    path_request r;
+    const char* p = req.c_str();
+    char* end = nullptr;
+    auto next = [&](float& v) {
+        v = std::strtof(p, &end);
+        const bool ok = end != p;
+        p = end;
+        return ok;
+    };
+    if (!(next(r.acc_min) && next(r.acc_max) && next(r.vel_min) && next(r.vel_max))) throw std::invalid_argument("path request: four limits expected");
+    float x, y;
+    while (next(x) && next(y)) {
+        r.max_x = std::max(r.max_x, std::fabs(x));
+        r.max_y = std::max(r.max_y, std::fabs(y));
+        r.path.push_back(Vector2f(x, y));
+    }
+    return r;
+}
+
+// Reply of the service: a JSON array with one state per sample, the keys of serialize_path_to_json (:1423-1457).  (The
+// reference flattens vel / acc through format_vec_vecx, which repeats element [i] of DOF i for every sample (:1414);
+// this writes the per-sample values.)  Floats are printed with 9 significant digits, which round-trips float32.
+inline std::string serialize_path_to_json(const bezier_spline& spline, const velocity_profile& vel_prof, const arclength_data& arclens,
+                                          const std::vector<float>& ang_vel) {
+    (void)arclens;
+    std::string out = "[";
+    char buf[512];
+    const size_t n = spline.pts.size();
+    for (size_t i = 0; i < n; ++i) {
+        std::snprintf(buf, sizeof(buf),
+                      "%s{\"acceleration\":%.9g,\"angularVelocity\":%.9g,\"holonomicAngularVelocity\":0.0,\"holonomicRotation\":0.0,"
+                      "\"pose\":{\"translation\":{\"x\":%.9g,\"y\":%.9g}},\"time\":%.9g,\"velocity\":%.9g}",
+                      i ? "," : "", (double)vel_prof.acc[0](i), (double)ang_vel[i], (double)spline.pts[i].x(), (double)spline.pts[i].y(),
+                      (double)(float)vel_prof.time(i), (double)vel_prof.vel[0](i));
+        out += buf;
+    }
+    out += "]";
+    return out;
 }
 
 }  // namespace turtle::sc

@@ -13,7 +13,30 @@ using namespace turtle::sc;
         if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } \
     } while (0)
 
-int main() {
+// `test_header --serve-recorded-request`: what examples/zmq_test.cpp:25-101 does for the request of examples/zmq_test.py:7-10,
+// reply on stdout.
+static int serve_recorded_request() {
+    const path_request rq = parse_path_request("-0.5 0.5 -0.25 0.25\n0 0\n10 0\n10 10");
+    if (rq.path.size() != 3 || rq.acc_min != -0.5f || rq.vel_max != 0.25f || rq.max_x != 10.f || rq.max_y != 10.f) return 2;
+    const bounding_rect brq = {rq.max_x, -rq.max_x, rq.max_y, -rq.max_y};
+    planning_space sp(brq);
+    bezier_spline pad = bezier_spline::from_path(rq.path, sp);
+    const arclength_data ad = pad.arclength();
+    auto lim = [&](value_type) {
+        toppra_compat::Vector lo(1), hi(1);
+        lo(0) = rq.vel_min; hi(0) = rq.vel_max;
+        return std::make_tuple(lo, hi);
+    };
+    velocity_profile prof = gen_vel_prof<1>(VectorNd<1>{ad.arclength}, VectorNd<1>{0}, VectorNd<1>{0}, VectorNd<1>{0}, lim,
+                                            VectorNd<1>{rq.acc_min}, VectorNd<1>{rq.acc_max});
+    bezier_spline re = pad.resample(prof.pos[0], ad, true);
+    const std::vector<float> w = re.angular_velocity(prof);
+    std::fputs(serialize_path_to_json(re, prof, ad, w).c_str(), stdout);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--serve-recorded-request") return serve_recorded_request();
     // --- planning path: examples/test.cpp:249-284 ---
     const bounding_rect br = {1, -1, 1, -1};
     planning_space space(br);

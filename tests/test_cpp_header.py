@@ -41,3 +41,25 @@ def test_header_end_to_end_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_service_reply_matches_recorded_output(tmp_path, golden_dir):
+    """The example service's request -> reply (examples/zmq_test.cpp:25-101) through the successor header, against the
+    reference's recorded run (examples/output.json; it predates the per-state reply schema, so values are compared)."""
+    import json
+    import numpy as np
+    exe = _build(tmp_path, "c++20")
+    r = subprocess.run([exe, "--serve-recorded-request"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    states = json.loads(r.stdout)
+    fx = np.load(os.path.join(golden_dir, "toppra_1dof_output.npz"))
+    assert len(states) == fx["time"].shape[0] == 4328
+    assert set(states[0]) == {"time", "velocity", "acceleration", "angularVelocity", "pose", "holonomicRotation", "holonomicAngularVelocity"}
+    col = lambda f: np.array([f(s) for s in states])
+    assert np.abs(col(lambda s: s["time"]) - fx["time"]).max() < 2e-5
+    assert np.abs(col(lambda s: s["velocity"]) - fx["vel"]).max() < 2e-6
+    assert np.abs(col(lambda s: s["acceleration"]) - fx["acc"]).max() < 2e-6
+    assert np.abs(col(lambda s: s["angularVelocity"]) - fx["ang_vel"]).max() < 2e-6
+    assert np.abs(col(lambda s: s["pose"]["translation"]["x"]) - fx["pos_x"]).max() < 5e-5
+    assert np.abs(col(lambda s: s["pose"]["translation"]["y"]) - fx["pos_y"]).max() < 5e-5
