@@ -499,22 +499,28 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             }
         }
         bool saturated = false;
-        for (int it = 1; it <= 255; ++it) {
+        // One cascade step.  All eight neighbour minima are formed from the old values before any register is updated:
+        // no dependent packed instruction follows its producer directly (each such pair costs a wait state) and no
+        // register has to be copied to keep the previous value alive.
+        auto cascade_step = [&](int it) {
             const uint32_t c = (uint32_t)(2 * it - 1) * 0x00010001u;
             const uint32_t T = P[HP - 1], S = P[0];
             const uint32_t below = from_lane_below(T, 0xFFFFFFFFu);
             const uint32_t above = from_lane_above(S, 0xFFFFFFFFu);
             const uint32_t L0 = __builtin_amdgcn_alignbit(T, below, 16);
             const uint32_t RL = __builtin_amdgcn_alignbit(above, S, 16);
-            uint32_t prev = L0;
+            uint32_t m[HP];
 #pragma unroll
-            for (int j = 0; j < HP; ++j) {
-                const uint32_t cur = P[j];
-                const uint32_t nxt = j < HP - 1 ? P[j + 1] : RL;
-                P[j] = pk_min(cur, pk_add_sat(pk_min(prev, nxt), c));
-                prev = cur;
-            }
-            if ((it & 1) == 0 && (it <= 12 || (it & 3) == 0)) {
+            for (int j = 0; j < HP; ++j) m[j] = pk_min(j ? P[j - 1] : L0, j < HP - 1 ? P[j + 1] : RL);
+#pragma unroll
+            for (int j = 0; j < HP; ++j) m[j] = pk_add_sat(m[j], c);
+#pragma unroll
+            for (int j = 0; j < HP; ++j) P[j] = pk_min(P[j], m[j]);
+        };
+        for (int it = 2; it <= 256; it += 2) {
+            cascade_step(it - 1);
+            cascade_step(it);
+            if (it <= 12 || (it & 3) == 0) {
                 uint32_t m;
                 if (FULL) {
                     m = P[0];
