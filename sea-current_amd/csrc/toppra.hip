@@ -27,6 +27,7 @@ struct toppra_args {
     int P, dof, N;
     const double *p0, *p1, *v0, *v1, *vlo, *vhi, *alo, *ahi;
     int vlim_per_stage;
+    int lds_limits;   // 1: all velocity limits, the acceleration limits and K are staged in LDS (dynamic LDS sized by the host)
     double sd_start, sd_end;
     double *K, *x, *u, *t;
     int32_t* status;
@@ -47,9 +48,23 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     __shared__ double s_al[TP_MAXROWS], s_be[TP_MAXROWS], s_ga[TP_MAXROWS];
     __shared__ double s_c1[TP_MAXDOF], s_c2[TP_MAXDOF], s_c3[TP_MAXDOF];
     __shared__ int s_up[TP_MAXROWS], s_lw[TP_MAXROWS];
+    __shared__ double s_alo[TP_MAXDOF], s_ahi[TP_MAXDOF];
+    extern __shared__ double s_dyn[];   // lds_limits: vlo [(N+1) or 1][dof], vhi [same], K [N+1][2]
     const int lane = threadIdx.x, p = blockIdx.x;
     const int dof = a.dof, N = a.N;
     const int nr = 4 * dof + 2;
+    // A sweep is a chain of N dependent stages; a stage that waits for limits from HBM (a fresh line per stage) or for
+    // the previous sweep's K costs more than its arithmetic.  Everything a stage reads is therefore staged in LDS once,
+    // with coalesced loads, before the sweeps start.
+    const int nv = (a.vlim_per_stage ? (N + 1) : 1) * dof;
+    double* s_vlo = s_dyn;
+    double* s_vhi = s_dyn + nv;
+    double* s_K = s_dyn + 2 * nv;
+    if (a.lds_limits) {
+        const size_t vo = a.vlim_per_stage ? (size_t)p * (N + 1) * dof : (size_t)p * dof;
+        for (int k = lane; k < nv; k += 64) { s_vlo[k] = a.vlo[vo + k]; s_vhi[k] = a.vhi[vo + k]; }
+    }
+    if (lane < dof) { s_alo[lane] = a.alo[(size_t)p * dof + lane]; s_ahi[lane] = a.ahi[(size_t)p * dof + lane]; }
     if (lane < dof) {
         const size_t o = (size_t)p * dof + lane;
         const double d = a.p1[o] - a.p0[o], v0 = a.v0[o], v1 = a.v1[o];
@@ -70,8 +85,14 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         double sdmin = -TP_MAXSD, sdmax = TP_MAXSD;
         if (lane < dof) {
             const double v = s_c1[lane] + s * (2.0 * s_c2[lane] + s * 3.0 * s_c3[lane]);
-            const size_t o = a.vlim_per_stage ? ((size_t)p * (N + 1) + i) * dof + lane : (size_t)p * dof + lane;
-            const double lo = a.vlo[o], hi = a.vhi[o];
+            double lo, hi;
+            if (a.lds_limits) {
+                const int o = a.vlim_per_stage ? i * dof + lane : lane;
+                lo = s_vlo[o]; hi = s_vhi[o];
+            } else {
+                const size_t o = a.vlim_per_stage ? ((size_t)p * (N + 1) + i) * dof + lane : (size_t)p * dof + lane;
+                lo = a.vlo[o]; hi = a.vhi[o];
+            }
             if (v > 0) { sdmax = fmin(hi / v, sdmax); sdmin = fmax(lo / v, sdmin); }
             else if (v < 0) { sdmax = fmin(lo / v, sdmax); sdmin = fmax(hi / v, sdmin); }
         }
@@ -91,9 +112,8 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
                     aa = an + 2.0 * D * bn;
                     bb = bn;
                 }
-                const size_t o = (size_t)p * dof + k;
-                if (var & 1) { al = -aa; be = -bb; ga = -a.alo[o]; }
-                else { al = aa; be = bb; ga = a.ahi[o]; }
+                if (var & 1) { al = -aa; be = -bb; ga = -s_alo[k]; }
+                else { al = aa; be = bb; ga = s_ahi[k]; }
             } else if (r == 4 * dof) { al = 2.0 * D; be = 1.0; ga = khi; }
             else { al = -2.0 * D; be = -1.0; ga = -klo; }
             s_al[r] = al; s_be[r] = be; s_ga[r] = ga;
@@ -105,6 +125,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     // ---- backward pass: controllable sets ----
     double klo = a.sd_end * a.sd_end, khi = klo;
     if (lane == 0) { K[2 * N] = klo; K[2 * N + 1] = khi; }
+    if (a.lds_limits && lane == 0) { s_K[2 * N] = klo; s_K[2 * N + 1] = khi; }
     for (int i = N - 1; i >= 0; --i) {
         double lo, hi;
         build(i, klo, khi, lo, hi);
@@ -144,6 +165,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         klo = lo > 0 ? lo : 0.0;
         khi = hi;
         if (lane == 0) { K[2 * i] = klo; K[2 * i + 1] = khi; }
+        if (a.lds_limits && lane == 0) { s_K[2 * i] = klo; s_K[2 * i + 1] = khi; }
         __syncthreads();
     }
     // ---- forward pass: greedy maximal u, knot times ----
@@ -153,7 +175,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         if (x < klo - TP_LP_TOL || x > khi + TP_LP_TOL) status = 2;
         if (lane == 0) { X[0] = x; T[0] = 0.0; }
         for (int i = 0; i < N && !status; ++i) {
-            const double nlo = K[2 * (i + 1)], nhi = K[2 * (i + 1) + 1];
+            const double nlo = a.lds_limits ? s_K[2 * (i + 1)] : K[2 * (i + 1)], nhi = a.lds_limits ? s_K[2 * (i + 1) + 1] : K[2 * (i + 1) + 1];
             double lo, hi;
             build(i, nlo, nhi, lo, hi);
             double umax = INFINITY, umin = -INFINITY;
@@ -189,10 +211,12 @@ extern "C" int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
         !alim_lo || !alim_hi || !K || !x || !u || !t || !status)
         return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    toppra_args a{P, dof, N, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, vlim_per_stage,
+    const size_t lds = ((size_t)2 * (vlim_per_stage ? (N + 1) : 1) * dof + (size_t)2 * (N + 1)) * sizeof(double);
+    const int lds_limits = lds <= 56 * 1024 ? 1 : 0;   // otherwise the sweeps read limits and K from global memory
+    toppra_args a{P, dof, N, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, vlim_per_stage, lds_limits,
                   sd_start, sd_end, K, x, u, t, status};
     int tk = sc_time_begin(ctx, SC_K_TOPPRA);
-    hipLaunchKernelGGL(toppra_kernel, dim3(P), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(toppra_kernel, dim3(P), dim3(64), lds_limits ? lds : 0, ctx->stream, a);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
