@@ -52,9 +52,8 @@ __global__ void __launch_bounds__(256)
 edt_nearest_kernel(const uint8_t* __restrict__ occ, const int32_t* __restrict__ d2, int W, int H, int32_t* __restrict__ nearest) {
     const size_t cells = (size_t)W * H;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= cells * gridDim.y) return;
-    const size_t gi = (size_t)blockIdx.y * cells + i;
     if (i >= cells) return;
+    const size_t gi = (size_t)blockIdx.y * cells + i;
     const uint8_t* o = occ + (size_t)blockIdx.y * cells;
     const int x = (int)(i % W), y = (int)(i / W);
     const int32_t D = d2[gi];
