@@ -226,6 +226,10 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int lh = 0, lt = 1;  // LDS ring of the current f (wave-uniform)
+    // Register copy of the 32 HBM ring heads / tails, bucket i in lane i: the drain loop and the search for the next
+    // non-empty level read them with v_readlane / one ballot instead of a chain of dependent LDS reads per level.
+    // Heads only move in wave-uniform code; tails move by LDS atomics during a step and are re-read once after it.
+    int rh = 0, rt = 0;
 
     bool found = false, overflow = false, ovf = false;
     int nexp = 0, niter = 0;
@@ -245,8 +249,8 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
             int hd = 0;
             if (lt != lh) { n = min(64, lt - lh); from_lds = true; }
             else {
-                hd = HEAD(b);
-                const int tl = TAIL(b);
+                hd = __builtin_amdgcn_readlane(rh, b);
+                const int tl = __builtin_amdgcn_readlane(rt, b);
                 if (hd == tl) break;
                 n = min(64, tl - hd);
                 from_lds = false;
@@ -301,6 +305,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                         mv[k] = mm[k] & ~entry_prune(de[k]);
                     }
                     if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (lane == b) rh = hd + n;
                 }
 #ifdef ASTAR_STAMPS
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -406,6 +411,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     valid = valid && (gv & ~gmask) == etag && (int)(gc + octile(cx, cy, gx, gy)) == fcur;
                     mv = mm & ~entry_prune(de);
                     if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (lane == b) rh = hd + n;
                 }
                 if (!valid) mv = 0;
                 const int c = cy * W + cx;
@@ -466,11 +472,13 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
             else if (K == 2) step(std::integral_constant<int, 2>{});
             else step_wide();
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            rt = TAIL(lane & 31);
             if (__ballot(ovf)) { overflow = true; break; }
         }
         if (overflow || found) break;
         // level fcur is exhausted: advance to the next non-empty bucket
-        const uint32_t nonempty = (uint32_t)__ballot(lane < NBUCKET && HEAD(lane & 31) != TAIL(lane & 31));   // bit i = bucket i
+        const uint32_t nonempty = (uint32_t)__ballot(lane < NBUCKET && rh != rt);   // bit i = bucket i
         if (nonempty == 0) break;  // open list empty: no path
         const int r0 = (fcur + 1) & 31;
         const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
@@ -478,7 +486,10 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     }
     dbg_iter = niter;
 #ifdef ASTAR_STAMPS
-    if (lane == 0 && a.dbg) { a.dbg[2 * q] = (int)(st_pop >> 10); a.dbg[2 * q + 1] = (int)(st_mem >> 10); a.expanded[q] = (int)(st_rest >> 10); a.status[q] = niter; }
+    if (lane == 0 && a.dbg) {
+        a.dbg[2 * q] = (int)(st_pop >> 10); a.dbg[2 * q + 1] = (int)(st_mem >> 10); a.expanded[q] = (int)(st_rest >> 10); a.status[q] = niter;
+        a.cost[q] = (int)((__builtin_amdgcn_s_memtime() - dbg_t0) >> 10);   // whole search, same clock
+    }
     return;
 #endif
 

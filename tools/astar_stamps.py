@@ -5,7 +5,7 @@ os.environ["SC_ASTAR_DEBUG"] = "1"
 import numpy as np, torch
 import sea_current_amd as sc
 from sea_current_amd import synth
-sc.LIB_PATH = os.path.join(ROOT, "sea-current_amd", "libsc_stamps.so")
+sc.LIB_PATH = os.path.join(ROOT, "sea-current_amd", sys.argv[1] if len(sys.argv) > 1 else "libsc_stamps.so")
 ctx = sc.Context(0)
 occ = synth.salt_grid(1024, 1024, 0.2)
 d2 = ctx.edt(torch.from_numpy(occ).cuda()); torch.cuda.synchronize()
@@ -16,4 +16,4 @@ for j in (5, 17):
     torch.cuda.synchronize()
     ex, it = ctx.astar_debug_stats(1)
     n = int(out["status"][0])
-    print("query", j, "iters", n, "cycles/iter: pop %.0f  mem %.0f  rest %.0f" % (it[0, 0] * 1024.0 / n, it[0, 1] * 1024.0 / n, ex[0] * 1024.0 / n))
+    print("query", j, "iters", n, "ticks/iter: pop %.0f  mem %.0f  rest %.0f  | whole search %.0f" % (it[0, 0] * 1024.0 / n, it[0, 1] * 1024.0 / n, ex[0] * 1024.0 / n, int(out["cost"][0]) * 1024.0 / n))
