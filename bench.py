@@ -288,6 +288,22 @@ def main():
 
         legs = {fam: edt_leg(fam) for fam in ("salt05", "salt20", "blocks")}
         result["roofline"] = legs[args.map]
+        # measured device-to-device copy bandwidth on this box (256 MiB read + 256 MiB written per copy), for scale
+        src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(20):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * src.numel() * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        result["roofline"]["measured_copy_GBps"] = copy_gbs
+        result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / copy_gbs
+        del src, dst
         tpath = os.path.join(ROOT, "profiles", "edt_traffic.json")
         if os.path.exists(tpath) and (W, H, args.edt_batch) == (1024, 1024, 64):
             try:
