@@ -33,17 +33,33 @@ struct toppra_args {
     int32_t* status;
 };
 
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+// Wave-wide min / max of doubles through DPP lane moves (a few cycles each) instead of ds_bpermute shuffles (an LDS
+// crossbar round trip each): a sweep is a chain of ~10 dependent reductions per stage, and the shuffle latency alone was
+// most of a stage.  Butterfly inside each row of 16 lanes (quad_perm, half mirror, mirror), then row_bcast:15 / :31
+// carry the row results upwards; lane 63 ends with the result, which is broadcast through an SGPR.  min / max are exact
+// and order independent, so results are bit-identical to any other reduction order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+template <bool IS_MIN>
+__device__ __forceinline__ double wave_minmax(double v) {
+    auto op = [](double a, double b) { return IS_MIN ? fmin(a, b) : fmax(a, b); };
+    v = op(v, dpp_f64<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+    v = op(v, dpp_f64<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+    v = op(v, dpp_f64<0x141, 0xF>(v));   // row_half_mirror
+    v = op(v, dpp_f64<0x140, 0xF>(v));   // row_mirror: every lane of a row holds the row's result
+    v = op(v, dpp_f64<0x142, 0xA>(v));   // row_bcast:15 -> rows 1 and 3
+    v = op(v, dpp_f64<0x143, 0xC>(v));   // row_bcast:31 -> rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double wave_min(double v) { return wave_minmax<true>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_minmax<false>(v); }
 
+template <bool LDSLIM>
 __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     __shared__ double s_al[TP_MAXROWS], s_be[TP_MAXROWS], s_ga[TP_MAXROWS];
     __shared__ double s_c1[TP_MAXDOF], s_c2[TP_MAXDOF], s_c3[TP_MAXDOF];
@@ -60,7 +76,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     double* s_vlo = s_dyn;
     double* s_vhi = s_dyn + nv;
     double* s_K = s_dyn + 2 * nv;
-    if (a.lds_limits) {
+    if (LDSLIM) {
         const size_t vo = a.vlim_per_stage ? (size_t)p * (N + 1) * dof : (size_t)p * dof;
         for (int k = lane; k < nv; k += 64) { s_vlo[k] = a.vlo[vo + k]; s_vhi[k] = a.vhi[vo + k]; }
     }
@@ -86,7 +102,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         if (lane < dof) {
             const double v = s_c1[lane] + s * (2.0 * s_c2[lane] + s * 3.0 * s_c3[lane]);
             double lo, hi;
-            if (a.lds_limits) {
+            if (LDSLIM) {
                 const int o = a.vlim_per_stage ? i * dof + lane : lane;
                 lo = s_vlo[o]; hi = s_vhi[o];
             } else {
@@ -125,7 +141,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     // ---- backward pass: controllable sets ----
     double klo = a.sd_end * a.sd_end, khi = klo;
     if (lane == 0) { K[2 * N] = klo; K[2 * N + 1] = khi; }
-    if (a.lds_limits && lane == 0) { s_K[2 * N] = klo; s_K[2 * N + 1] = khi; }
+    if (LDSLIM && lane == 0) { s_K[2 * N] = klo; s_K[2 * N + 1] = khi; }
     for (int i = N - 1; i >= 0; --i) {
         double lo, hi;
         build(i, klo, khi, lo, hi);
@@ -149,8 +165,12 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
             }
         }
         __syncthreads();
+        const float inv_nl = nl > 0 ? 1.0f / (float)nl : 0.f;
         for (int pi = lane; pi < nu * nl; pi += 64) {
-            const int ri = s_up[pi / nl], rj = s_lw[pi % nl];
+            // pi / nl without the integer-division expansion: pi < 66 * 66, so the float quotient of (pi + 0.5) is
+            // at least 0.5 / 66 away from an integer and truncates to the exact result
+            const int qi = (int)(((float)pi + 0.5f) * inv_nl);
+            const int ri = s_up[qi], rj = s_lw[pi - qi * nl];
             const double ali = s_al[ri], bei = s_be[ri], gai = s_ga[ri];
             const double alj = s_al[rj], bej = s_be[rj], gaj = s_ga[rj];
             const double cf = alj * bei - ali * bej, rhs = alj * gai - ali * gaj;
@@ -165,7 +185,7 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         klo = lo > 0 ? lo : 0.0;
         khi = hi;
         if (lane == 0) { K[2 * i] = klo; K[2 * i + 1] = khi; }
-        if (a.lds_limits && lane == 0) { s_K[2 * i] = klo; s_K[2 * i + 1] = khi; }
+        if (LDSLIM && lane == 0) { s_K[2 * i] = klo; s_K[2 * i + 1] = khi; }
         __syncthreads();
     }
     // ---- forward pass: greedy maximal u, knot times ----
@@ -175,7 +195,9 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
         if (x < klo - TP_LP_TOL || x > khi + TP_LP_TOL) status = 2;
         if (lane == 0) { X[0] = x; T[0] = 0.0; }
         for (int i = 0; i < N && !status; ++i) {
-            const double nlo = a.lds_limits ? s_K[2 * (i + 1)] : K[2 * (i + 1)], nhi = a.lds_limits ? s_K[2 * (i + 1) + 1] : K[2 * (i + 1) + 1];
+            double nlo, nhi;
+            if (LDSLIM) { nlo = s_K[2 * (i + 1)]; nhi = s_K[2 * (i + 1) + 1]; }
+            else { nlo = K[2 * (i + 1)]; nhi = K[2 * (i + 1) + 1]; }
             double lo, hi;
             build(i, nlo, nhi, lo, hi);
             double umax = INFINITY, umin = -INFINITY;
@@ -216,7 +238,8 @@ extern "C" int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
     toppra_args a{P, dof, N, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, vlim_per_stage, lds_limits,
                   sd_start, sd_end, K, x, u, t, status};
     int tk = sc_time_begin(ctx, SC_K_TOPPRA);
-    hipLaunchKernelGGL(toppra_kernel, dim3(P), dim3(64), lds_limits ? lds : 0, ctx->stream, a);
+    if (lds_limits) hipLaunchKernelGGL(toppra_kernel<true>, dim3(P), dim3(64), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(toppra_kernel<false>, dim3(P), dim3(64), 0, ctx->stream, a);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
