@@ -394,6 +394,10 @@ def main():
             if k == 0:
                 ref0 = ref
             k += 1
+        # single-thread figure (the reference is single-threaded): the first 128 queries of set 0
+        t0 = time.perf_counter()
+        oracle.astar_batch(d2_ref, s_h[:128], g_h[:128], Lmax=args.lmax, nthreads=1)
+        t_1 = time.perf_counter() - t0
         # parity spot-check of what was just timed on the GPU (set 0 = the same queries)
         pth = out["path"].cpu().numpy()
         ok = bool(np.array_equal(ref0["status"], st) and np.array_equal(ref0["cost"], out["cost"].cpu().numpy())
@@ -403,6 +407,7 @@ def main():
                                             f"A* on {cores} threads: {t_as:.1f} s in total); build's own C restatement -- "
                                             "the reference has no grid path",
                                   "edt_seconds_1thread": t_edt, "astar_expansions": nexp,
+                                  "single_thread_value": 128 / (t_edt * 128 / Qloc + t_1),
                                   "gpu_matches_cpu_on_sample": ok}
     if rank == 0:
         print(json.dumps(result))
