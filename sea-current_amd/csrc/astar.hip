@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     bool found = false, overflow = false, ovf = false;
     int nexp = 0, niter = 0;
 #ifdef ASTAR_STAMPS
-    unsigned long long st_pop = 0, st_mem = 0, st_rest = 0;
+    unsigned long long st_pop = 0, st_mem = 0, st_rest = 0, st_wide = 0;
+    int n_wide = 0, n_hbm = 0;
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
     dbg_t0 = __builtin_amdgcn_s_memtime();
@@ -468,9 +469,16 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
                     }
                 }
             };
+#ifdef ASTAR_STAMPS
+            if (!from_lds) ++n_hbm;
+            const unsigned long long tw0 = STAMP();
+#endif
             if (K == 1) step(std::integral_constant<int, 1>{});
             else if (K == 2) step(std::integral_constant<int, 2>{});
             else step_wide();
+#ifdef ASTAR_STAMPS
+            if (K > 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_wide += STAMP() - tw0; ++n_wide; }
+#endif
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             rt = TAIL(lane & 31);
@@ -489,6 +497,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     if (lane == 0 && a.dbg) {
         a.dbg[2 * q] = (int)(st_pop >> 10); a.dbg[2 * q + 1] = (int)(st_mem >> 10); a.expanded[q] = (int)(st_rest >> 10); a.status[q] = niter;
         a.cost[q] = (int)((__builtin_amdgcn_s_memtime() - dbg_t0) >> 10);   // whole search, same clock
+        a.len[q] = n_wide; path[0] = (int)(st_wide >> 10); path[1] = n_hbm;
     }
     return;
 #endif

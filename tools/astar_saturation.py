@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "sea-current_amd", "python")); sys.path.in
 os.environ["SC_ASTAR_DEBUG"] = "1"
 import numpy as np, torch, time
 import sea_current_amd as sc
+if os.environ.get('SC_LIB'): sc.LIB_PATH = os.path.join(sc.NATIVE_DIR, os.environ['SC_LIB'])
 from sea_current_amd import synth
 ctx = sc.Context(0)
 fam = sys.argv[1] if len(sys.argv) > 1 else "salt20"
