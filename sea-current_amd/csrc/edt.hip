@@ -133,7 +133,12 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
     uint32_t* cw = smem;              // [COLN] band's own column words
     uint32_t* cud = cw + COLN;        // [COLN] up | dn << 16: rows to the nearest obstacle above the band top / below its bottom
     uint32_t* trs = cud + COLN;       // [WAVES][TRN]
-    const int b = blockIdx.x % nb, g = blockIdx.x / nb;
+    // Workgroups are dealt to the 8 XCDs round-robin, each XCD with its own L2.  Remap so that an XCD works through a
+    // contiguous range of (grid, band) pairs: the column words of neighbouring bands that the look-back re-reads are
+    // then found in the same L2 instead of being fetched once per XCD.
+    const unsigned nwg = gridDim.x, per = nwg >> 3;
+    const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
     // ---- phase 1: per column, nearest obstacle above / below the band (look-back over band words) ----
@@ -379,7 +384,12 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     extern __shared__ uint32_t smem[];
     uint8_t* g8 = reinterpret_cast<uint8_t*>(smem);            // [32][WP]
     uint32_t* trs = smem + 32 * WP / 4;                        // [WAVES][TRN]
-    const int b = blockIdx.x % nb, g = blockIdx.x / nb;
+    // Workgroups are dealt to the 8 XCDs round-robin, each XCD with its own L2.  Remap so that an XCD works through a
+    // contiguous range of (grid, band) pairs: the column words of neighbouring bands that the look-back re-reads are
+    // then found in the same L2 instead of being fetched once per XCD.
+    const unsigned nwg = gridDim.x, per = nwg >> 3;
+    const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
 #ifdef EDT_ABLATE_PHASE1   // timing-only: no look-back / recurrence, constant distances
