@@ -551,13 +551,18 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             }
         }
         if (!saturated) {
-            // packed transpose: lane writes its HP packed registers, reads back u16 halves so that
-            // each lane then holds 4 consecutive pixels for one 16-byte store.  PPL == 16: unpadded
-            // 8-dword rows with an XOR swizzle of the register index (bank-conflict free both ways).
+            // packed transpose: lane writes its HP packed registers and reads back the halves it needs so that
+            // each lane then holds 4 consecutive pixels for one 16-byte store
+            if constexpr (PPL == 16) {
+                // two 16-byte chunks per lane (registers 0-3 and 4-7), swapped in every other group of four lanes: eight
+                // consecutive lanes then cover all 32 banks exactly once, for the writes and for the reads below
+                uint32_t* wb = (lane < 32 ? tr : trb) + 8 * lane;
+                const int s = (lane >> 2) & 1;
+                *reinterpret_cast<uint4*>(wb + 4 * s) = make_uint4(P[0], P[1], P[2], P[3]);
+                *reinterpret_cast<uint4*>(wb + 4 * (1 - s)) = make_uint4(P[4], P[5], P[6], P[7]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < HP; ++j) {
-                if constexpr (PPL == 16) (lane < 32 ? tr : trb)[8 * lane + (j ^ ((lane >> 2) & 7))] = P[j];
-                else tr[(HP + 1) * lane + j] = P[j];
+                for (int j = 0; j < HP; ++j) tr[(HP + 1) * lane + j] = P[j];
             }
             wave_lds_sync();
             const uint16_t* trh = reinterpret_cast<const uint16_t*>(tr);
@@ -567,10 +572,13 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                 const int l2 = x / PPL, j2 = x % PPL;                    // owner lane, pixel index there
                 int4 v;
                 if constexpr (PPL == 16) {
-                    const uint16_t* trh = reinterpret_cast<const uint16_t*>(l2 < 32 ? tr : trb);
-                    const int sw = (l2 >> 2) & 7, r0 = j2 % HP, hf = j2 >= HP ? 1 : 0;
-                    v = make_int4(trh[2 * (8 * l2 + ((r0 + 0) ^ sw)) + hf], trh[2 * (8 * l2 + ((r0 + 1) ^ sw)) + hf],
-                                  trh[2 * (8 * l2 + ((r0 + 2) ^ sw)) + hf], trh[2 * (8 * l2 + ((r0 + 3) ^ sw)) + hf]);
+                    // owner lane l2 = 16 k + lane / 4; its chunk (lane & 1) sits at 4 * ((lane & 1) ^ ((l2 >> 2) & 1)) and
+                    // (l2 >> 2) & 1 == (lane >> 4) & 1 for every k: one base address per lane, k only adds 512 bytes
+                    const uint32_t* rb = (k < 2 ? tr : trb) + 8 * l2 + 4 * ((lane & 1) ^ ((lane >> 4) & 1));
+                    const uint4 q = *reinterpret_cast<const uint4*>(rb);
+                    const uint32_t sh = (lane & 2) ? 16u : 0u;   // pixels 8..15 are the high halves
+                    v = make_int4((int)__builtin_amdgcn_ubfe(q.x, sh, 16), (int)__builtin_amdgcn_ubfe(q.y, sh, 16),
+                                  (int)__builtin_amdgcn_ubfe(q.z, sh, 16), (int)__builtin_amdgcn_ubfe(q.w, sh, 16));
                 } else {
                     const int hidx = 2 * ((HP + 1) * l2 + (j2 % HP)) + (j2 >= HP ? 1 : 0);
                     v = make_int4(trh[hidx], trh[hidx + 2], trh[hidx + 4], trh[hidx + 6]);
