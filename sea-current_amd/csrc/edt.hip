@@ -111,6 +111,9 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
 }
+__device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, b));
+}
 // lane l <- lane l-1 (lane 0 keeps `fill`) / lane l <- lane l+1 (lane 63 keeps `fill`)
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
@@ -447,13 +450,14 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
         // top-down: gu = rows to the nearest obstacle at or above, clamped at 255 and kept two rows per
         // VGPR (bytes: row 2m in [7:0] / [23:16], row 2m+1 in [15:8] / [31:24]) to stay within 64 VGPRs
         uint32_t GU2[16];
+        const uint32_t nwA = (nw[0] & 0xFFFFu) | (nw[1] << 16), nwB = (nw[0] >> 16) | (nw[1] & 0xFFFF0000u);
         uint32_t gu = (uint32_t)(up[0] - 1) | ((uint32_t)(up[1] - 1) << 16);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            // 0xFFFF per half whose cell is free in row i
-            const uint32_t keep = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)nw[1], i, 1),
-                                                        (uint32_t)__builtin_amdgcn_sbfe((int)nw[0], i, 1), 0x05040100u);
-            gu = pk_add_sat(gu, 0x00010001u) & keep;
+            // 1 per half whose cell is free in row i (rows 0..15 from nwA, 16..31 from nwB: both columns' bits of a
+            // row sit 16 apart, so one shift and one mask fetch them together); multiplying resets the others to 0
+            const uint32_t free01 = ((i < 16 ? nwA : nwB) >> (i & 15)) & 0x00010001u;
+            gu = pk_mul_lo(pk_add_sat(gu, 0x00010001u), free01);
             const uint32_t guc = pk_min(gu, 0x00FF00FFu);
             if (i & 1) GU2[i >> 1] |= guc << 8; else GU2[i >> 1] = guc;
         }
@@ -466,7 +470,8 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             const uint32_t cap = guc << 8;   // <= 0xFF00 per half
             gd = pk_min(pk_add_sat(gd, 0x00010001u), cap);
             const uint32_t gg = pk_min(guc, gd);
-            *reinterpret_cast<uint16_t*>(g8 + (size_t)i * WP + 2 * q) = (uint16_t)((gg & 0xFFu) | ((gg >> 8) & 0xFF00u));
+            // bytes 0 and 2 of gg (the two columns' distances) -> one halfword, with a single byte permute
+            *reinterpret_cast<uint16_t*>(g8 + (size_t)i * WP + 2 * q) = (uint16_t)__builtin_amdgcn_perm(0u, gg, 0x0C0C0200u);
         }
     }
     __syncthreads();
@@ -488,6 +493,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     if (threadIdx.x == 0) d2[((size_t)g * H + y0) * W] = g8[lane];
     if (true) return;
 #endif
+    int chk_from = 2;   // first cascade step after which this wave tests for convergence (adapted row by row)
     for (int i = wave; i < nrows; i += WAVES) {
         int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
         uint32_t P[HP];
@@ -527,29 +533,33 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
 #pragma unroll
             for (int j = 0; j < HP; ++j) P[j] = pk_min(P[j], m[j]);
         };
-        for (int it = 2; it <= 256; it += 2) {
-            cascade_step(it - 1);
+        // The convergence test costs a third of a step, so it only starts one step before the count the wave's previous
+        // row needed (rows of a band are alike), then runs every step for a while and every second / fourth step later.
+        // When to test only affects how many surplus steps run, never the result.
+        int it = 1;
+        for (; it <= 256; ++it) {
             cascade_step(it);
-            if (it <= 12 || (it & 3) == 0) {
-                uint32_t m;
-                if (FULL) {
-                    m = P[0];
+            if (it < chk_from) continue;
+            if (it >= chk_from + 4 && ((it & 1) || (it > 16 && (it & 3)))) continue;
+            uint32_t m;
+            if (FULL) {
+                m = P[0];
 #pragma unroll
-                    for (int j = 1; j < HP; ++j) m = pk_max(m, P[j]);
-                    m = max(m & 0xFFFFu, m >> 16);
-                } else {
-                    m = 0;
+                for (int j = 1; j < HP; ++j) m = pk_max(m, P[j]);
+                m = max(m & 0xFFFFu, m >> 16);
+            } else {
+                m = 0;
 #pragma unroll
-                    for (int j = 0; j < HP; ++j) {
-                        if (j < nvalid) m = max(m, P[j] & 0xFFFFu);
-                        if (j + HP < nvalid) m = max(m, P[j] >> 16);
-                    }
+                for (int j = 0; j < HP; ++j) {
+                    if (j < nvalid) m = max(m, P[j] & 0xFFFFu);
+                    if (j + HP < nvalid) m = max(m, P[j] >> 16);
                 }
-                const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
-                if (__ballot(m > thr) == 0) break;
-                if (it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
             }
+            const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
+            if (__ballot(m > thr) == 0) break;
+            if (it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
         }
+        chk_from = max(2, min(it, 250) - 1);
         if (!saturated) {
             // packed transpose: lane writes its HP packed registers and reads back the halves it needs so that
             // each lane then holds 4 consecutive pixels for one 16-byte store
