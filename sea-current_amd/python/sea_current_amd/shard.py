@@ -29,9 +29,17 @@ def alloc_gather(out, world):
 
 
 def allgather_paths(out, gathered, dist, group=None):
-    """Fixed-stride all-gather of path/len/cost/status.  Every rank must hold the same Q_local."""
-    for k in ("len", "cost", "status", "path"):
-        dist.all_gather_into_tensor(gathered[k].view(-1), out[k].contiguous().view(-1), group=group)
+    """Fixed-stride all-gather of path/len/cost/status.  Every rank must hold the same Q_local.  Two collectives per
+    call: the three per-query int32 arrays travel as one [3, Q_local] block, the paths as the other."""
+    import torch
+    Q = out["len"].shape[0]
+    world = gathered["len"].shape[0] // max(Q, 1)
+    meta = torch.stack([out["len"], out["cost"], out["status"]])                     # [3, Q]
+    meta_all = torch.empty((world, 3, Q), dtype=meta.dtype, device=meta.device)
+    dist.all_gather_into_tensor(meta_all.view(-1), meta.contiguous().view(-1), group=group)
+    for j, k in enumerate(("len", "cost", "status")):
+        gathered[k].view(world, Q).copy_(meta_all[:, j, :])
+    dist.all_gather_into_tensor(gathered["path"].view(-1), out["path"].contiguous().view(-1), group=group)
     return gathered
 
 
