@@ -215,13 +215,23 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
                 // left neighbours of (pixel 0, pixel HP) and right neighbours of (pixel HP-1, pixel PPL-1)
                 const uint32_t L0 = __builtin_amdgcn_alignbit(T, below, 16);
                 const uint32_t RL = __builtin_amdgcn_alignbit(above, S, 16);
-                uint32_t prev = L0;
+                // in chunks of up to 8 registers: all neighbour minima of a chunk from the old values first, then the
+                // updates (no dependent packed pairs, no register copies); `left_old` carries the old value across chunks
+                constexpr int CH = HP < 8 ? HP : 8;
+                uint32_t left_old = L0;
 #pragma unroll
-                for (int j = 0; j < HP; ++j) {
-                    const uint32_t cur = P[j];
-                    const uint32_t nxt = j < HP - 1 ? P[j + 1] : RL;
-                    P[j] = pk_min(cur, pk_add_sat(pk_min(prev, nxt), c));
-                    prev = cur;
+                for (int j0 = 0; j0 < HP; j0 += CH) {
+                    uint32_t m[CH];
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) {
+                        const int j = j0 + t;
+                        m[t] = pk_min(t ? P[j - 1] : left_old, j < HP - 1 ? P[j + 1] : RL);
+                    }
+                    left_old = P[j0 + CH - 1];
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) m[t] = pk_add_sat(m[t], c);
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) P[j0 + t] = pk_min(P[j0 + t], m[t]);
                 }
                 if ((it & 3) == 0 || it <= 2) {
                     uint32_t m;
