@@ -45,7 +45,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
-    free_scratch(&ctx->colbits); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
+    free_scratch(&ctx->colbits); free_scratch(&ctx->edt_flags); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
     free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);

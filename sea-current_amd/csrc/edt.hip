@@ -124,7 +124,8 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t fill) {
 
 template <int PPL, bool FULL>
 __global__ void __launch_bounds__(256)
-edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
+edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2,
+                const int32_t* __restrict__ flags) {
     constexpr int WAVES = 4;
     constexpr int HP = PPL / 2;                    // packed registers per lane
     constexpr int G = PPL < 16 ? PPL : 16;         // pixels per lane per transpose pass
@@ -142,6 +143,7 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
     const unsigned nwg = gridDim.x, per = nwg >> 3;
     const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
+    if (flags && flags[g] == 0) return;   // second pass after the tiled kernel: only grids it gave up on
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
     // ---- phase 1: per column, nearest obstacle above / below the band (look-back over band words) ----
@@ -385,10 +387,19 @@ __device__ __noinline__ uint32_t edt_gdist_global(const uint32_t* cb, int W, int
     return min(gg, (uint32_t)EDT_G_INF);
 }
 
-template <int PPL, bool FULL>
+// TILED (rows wider than 1024, PPL == 16): a workgroup handles a window of 1024 columns of its band -- a core of
+// EDT_TILE_CORE columns plus EDT_TILE_HALO on either side.  After `it` cascade steps a core pixel has seen every site
+// within `it` columns, all of them inside the window, so the usual stopping rule holds as long as it <= EDT_TILE_HALO;
+// only the core is tested and stored.  A row that needs more steps (or leaves the packed range) raises flags[grid] and
+// the whole-row kernel redoes that grid afterwards.
+#define EDT_TILE_HALO 32
+#define EDT_TILE_CORE (1024 - 2 * EDT_TILE_HALO)
+template <int PPL, bool FULL, bool TILED = false>
 __global__ void __launch_bounds__(512, 8)
-edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
+edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2, int tiles,
+                   int32_t* __restrict__ flags) {
     static_assert(PPL == 8 || PPL == 16, "g8 path: 8 or 16 pixels per lane");
+    static_assert(!TILED || (PPL == 16 && FULL), "tiled windows are full 1024-column rows");
     constexpr int WAVES = 8;
     constexpr int HP = PPL / 2;
     constexpr int WP = 64 * PPL;
@@ -402,7 +413,11 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     // then found in the same L2 instead of being fetched once per XCD.
     const unsigned nwg = gridDim.x, per = nwg >> 3;
     const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
+    const int tile = TILED ? (int)(vid % (unsigned)tiles) : 0;
+    const unsigned bg = TILED ? vid / (unsigned)tiles : vid;
+    const int b = (int)(bg % (unsigned)nb), g = (int)(bg / (unsigned)nb);
+    const int xw0 = TILED ? tile * EDT_TILE_CORE - EDT_TILE_HALO : 0;   // global column of the window's first pixel
+    if (TILED && __hip_atomic_load(&flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // grid already given up
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
 #ifdef EDT_ABLATE_PHASE1   // timing-only: no look-back / recurrence, constant distances
@@ -419,24 +434,25 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             uint32_t w[2], wu[2][4], wd[2][4];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int x = 2 * q + c;
-                w[c] = x < W ? cb[(size_t)b * W + x] : 0u;
+                const int x = xw0 + 2 * q + c;
+                const bool in = x < W && (!TILED || x >= 0);
+                w[c] = in ? cb[(size_t)b * W + x] : 0u;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    wu[c][t] = (x < W && b - 1 - t >= 0) ? cb[(size_t)(b - 1 - t) * W + x] : 0u;
-                    wd[c][t] = (x < W && b + 1 + t < nb) ? cb[(size_t)(b + 1 + t) * W + x] : 0u;
+                    wu[c][t] = (in && b - 1 - t >= 0) ? cb[(size_t)(b - 1 - t) * W + x] : 0u;
+                    wd[c][t] = (in && b + 1 + t < nb) ? cb[(size_t)(b + 1 + t) * W + x] : 0u;
                 }
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int x = 2 * q + c;
+                const int x = xw0 + 2 * q + c;
                 up[c] = EDT_G_INF; dn[c] = EDT_G_INF;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (up[c] == EDT_G_INF && wu[c][t]) up[c] = (t + 1) * 32 - (31 - __clz((int)wu[c][t]));
                     if (dn[c] == EDT_G_INF && wd[c][t]) dn[c] = (t + 1) * 32 + (__ffs((int)wd[c][t]) - 1) - 31;
                 }
-                if (x < W) {
+                if (x < W && (!TILED || x >= 0)) {
                     for (int base = b - 5; base >= 0 && up[c] == EDT_G_INF; base -= 4) {
                         uint32_t ww[4];
 #pragma unroll
@@ -547,12 +563,24 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
         // row needed (rows of a band are alike), then runs every step for a while and every second / fourth step later.
         // When to test only affects how many surplus steps run, never the result.
         int it = 1;
-        for (; it <= 256; ++it) {
+        constexpr int IT_MAX = TILED ? EDT_TILE_HALO : 256;
+        for (; it <= IT_MAX; ++it) {
             cascade_step(it);
-            if (it < chk_from) continue;
+            if (it < chk_from && !(TILED && it == IT_MAX)) continue;
             if (it >= chk_from + 4 && ((it & 1) || (it > 16 && (it & 3)))) continue;
             uint32_t m;
-            if (FULL) {
+            if (TILED) {
+                // only core pixels that exist in the row count: lanes 2 .. 61, global column < W
+                m = 0;
+                const int nv = W - (xw0 + PPL * lane);
+                if (lane >= EDT_TILE_HALO / PPL && lane < 64 - EDT_TILE_HALO / PPL) {
+#pragma unroll
+                    for (int j = 0; j < HP; ++j) {
+                        if (j < nv) m = max(m, P[j] & 0xFFFFu);
+                        if (j + HP < nv) m = max(m, P[j] >> 16);
+                    }
+                }
+            } else if (FULL) {
                 m = P[0];
 #pragma unroll
                 for (int j = 1; j < HP; ++j) m = pk_max(m, P[j]);
@@ -567,9 +595,10 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             }
             const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
             if (__ballot(m > thr) == 0) break;
-            if (it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
+            if (!TILED && it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
         }
-        chk_from = max(2, min(it, 250) - 1);
+        if (TILED && it > IT_MAX) saturated = true;   // not settled within the halo: leave the grid to the whole-row kernel
+        chk_from = max(2, min(it, TILED ? IT_MAX - 1 : 250) - 1);
         if (!saturated) {
             // packed transpose: lane writes its HP packed registers and reads back the halves it needs so that
             // each lane then holds 4 consecutive pixels for one 16-byte store
@@ -603,7 +632,18 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                     const int hidx = 2 * ((HP + 1) * l2 + (j2 % HP)) + (j2 >= HP ? 1 : 0);
                     v = make_int4(trh[hidx], trh[hidx + 2], trh[hidx + 4], trh[hidx + 6]);
                 }
-                if (FULL || x + 3 < W) {
+                if constexpr (TILED) {
+                    const int xg = xw0 + x;   // global column; only the core of the window is stored
+                    if (x >= EDT_TILE_HALO && x < EDT_TILE_HALO + EDT_TILE_CORE) {
+                        if (xg + 3 < W && (((uintptr_t)(out + xg)) & 15) == 0) EDT_STORE4(out + xg, v);
+                        else {
+                            if (xg < W) out[xg] = v.x;
+                            if (xg + 1 < W) out[xg + 1] = v.y;
+                            if (xg + 2 < W) out[xg + 2] = v.z;
+                            if (xg + 3 < W) out[xg + 3] = v.w;
+                        }
+                    }
+                } else if (FULL || x + 3 < W) {
                     if (FULL || (((uintptr_t)(out + x)) & 15) == 0) EDT_STORE4(out + x, v);
                     else { out[x] = v.x; out[x + 1] = v.y; out[x + 2] = v.z; out[x + 3] = v.w; }
                 } else {
@@ -613,6 +653,8 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                 }
             }
             wave_lds_sync();
+        } else if constexpr (TILED) {
+            if (lane == 0) flags[g] = 1;
         } else {
             // ---- 32-bit cascade with exact distances (very sparse rows) ----
             uint32_t V[PPL];
@@ -666,7 +708,7 @@ static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, in
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_g8_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream,
-                       colbits, W, H, nb, d2);
+                       colbits, W, H, nb, d2, 1, (int32_t*)nullptr);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -679,7 +721,7 @@ static int launch_band_g8_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H
 }
 
 template <int PPL, bool FULL>
-static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, const int32_t* flags = nullptr) {
     constexpr int G = PPL < 16 ? PPL : 16;
     constexpr int WP = 64 * PPL;
     constexpr int TRN = (64 * (G + 1) > WP / 2 ? 64 * (G + 1) : WP / 2);
@@ -693,16 +735,36 @@ static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int n
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(256), lds, ctx->stream,
-                       colbits, W, H, nb, d2);
+                       colbits, W, H, nb, d2, flags);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
 
 template <int PPL>
-static int launch_band_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
-    return W == 64 * PPL ? launch_band<PPL, true>(ctx, colbits, W, H, nb, batch, d2)
-                         : launch_band<PPL, false>(ctx, colbits, W, H, nb, batch, d2);
+static int launch_band_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, const int32_t* flags = nullptr) {
+    return W == 64 * PPL ? launch_band<PPL, true>(ctx, colbits, W, H, nb, batch, d2, flags)
+                         : launch_band<PPL, false>(ctx, colbits, W, H, nb, batch, d2, flags);
+}
+
+// rows wider than 1024: windows of 1024 columns through the fast kernel; flags[grid] != 0 where it gave up
+static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, int32_t* flags) {
+    const int tiles = (W + EDT_TILE_CORE - 1) / EDT_TILE_CORE;
+    const size_t lds = (size_t)32 * 1024 + 8 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_g8_kernel<16, true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    SC_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)batch * sizeof(int32_t), ctx->stream));
+    int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+    ctx->edt_chain_token = -1;
+    hipLaunchKernelGGL((edt_band_g8_kernel<16, true, true>), dim3((unsigned)((size_t)nb * batch * tiles)), dim3(512), lds, ctx->stream,
+                       colbits, W, H, nb, d2, tiles, flags);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
 }
 
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2) {
@@ -735,9 +797,21 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
 #endif
     if (W <= 512) return launch_band_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 1024) return launch_band_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
-    if (W <= 2048) return launch_band_ppl<32>(ctx, colbits, W, H, nb, batch, d2);
-    if (W <= 4096) return launch_band_ppl<64>(ctx, colbits, W, H, nb, batch, d2);
-    return launch_band_ppl<128>(ctx, colbits, W, H, nb, batch, d2);
+    // wider rows: 1024-column windows through the fast kernel first, then the whole-row kernel for the grids (if any)
+    // in which some row did not settle within the window's halo
+    const int32_t* flags = nullptr;
+#ifndef EDT_NO_G8
+    {
+        r = sc_scratch_reserve(ctx, &ctx->edt_flags, (size_t)batch * sizeof(int32_t));
+        if (r != SC_OK) return r;
+        r = launch_band_g8_tiled(ctx, colbits, W, H, nb, batch, d2, (int32_t*)ctx->edt_flags.p);
+        if (r != SC_OK) return r;
+        flags = (const int32_t*)ctx->edt_flags.p;
+    }
+#endif
+    if (W <= 2048) return launch_band_ppl<32>(ctx, colbits, W, H, nb, batch, d2, flags);
+    if (W <= 4096) return launch_band_ppl<64>(ctx, colbits, W, H, nb, batch, d2, flags);
+    return launch_band_ppl<128>(ctx, colbits, W, H, nb, batch, d2, flags);
 }
 
 extern "C" int sc_edt_u8_i32(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2) {
