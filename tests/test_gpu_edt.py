@@ -116,3 +116,21 @@ def test_edt_nearest_matches_oracle(ctx, oracle):
     nb = ctx.edt_nearest(ob, d2b).cpu().numpy()
     for k in range(2):
         assert np.array_equal(nb[k], oracle.edt_nearest(ob[k].cpu().numpy(), d2b[k].cpu().numpy()))
+
+
+@pytest.mark.parametrize("W,H", [(1025, 40), (1984, 33), (2049, 70), (3000, 64)])
+def test_edt_wide_rows_windows_and_fallback(ctx, oracle, W, H):
+    """Rows wider than 1024 run in 1024-column windows; a grid with a row that does not settle within the halo is redone
+    by the whole-row kernel.  One batch mixes both kinds (the flag is per grid), plus an empty grid."""
+    import torch
+    rng = np.random.default_rng(W)
+    dense = (rng.random((H, W)) < 0.2).astype(np.uint8)
+    sparse = (rng.random((H, W)) < 2e-4).astype(np.uint8)             # distances far beyond the 32-column halo
+    edge = np.zeros((H, W), np.uint8); edge[:, 959:962] = 1; edge[H // 2, W - 1] = 1   # obstacles on a window seam
+    empty = np.zeros((H, W), np.uint8)
+    occ = np.stack([dense, sparse, edge, empty, dense[::-1].copy()])
+    d2 = ctx.edt(torch.from_numpy(occ).cuda())
+    torch.cuda.synchronize()
+    got = d2.cpu().numpy()
+    for b in range(occ.shape[0]):
+        assert np.array_equal(got[b], oracle.edt(occ[b])), b
