@@ -28,8 +28,14 @@
 // memset of the g arrays (4 MiB per query at 1024^2) disappears.
 //
 // The search runs until the f = C* bucket is exhausted (not merely until the goal is popped), which
-// makes the final g field -- and therefore the parent chain extracted from it -- independent of the
-// expansion order.
+// makes the final g of every expanded node -- and therefore the parent chain extracted from it --
+// independent of the expansion order.
+//
+// A full chip is bound by the rate of L2-missing atomics (profiles/r01_astar_saturation_pmc.json), so
+// the remaining design choices are about issuing fewer of them: g arrays are laid out in 4 x 4-cell
+// tiles (gix), successors that cannot receive their optimal g through this node are pruned when the
+// node is queued (prune_always / entry_prune: the neighbour pruning of jump point search), and the
+// relaxations of a step go out back to back under explicit EXEC masks (masked_atomic_min*).
 #include "sc_internal.h"
 #include <stdlib.h>
 #include <type_traits>
