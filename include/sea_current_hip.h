@@ -47,7 +47,9 @@ typedef enum {
     SC_Q_OK = 0,
     SC_Q_NO_PATH = 1,
     SC_Q_BAD_ENDPOINT = 2, /* start/goal out of range or not traversable */
-    SC_Q_TRUNCATED = 3     /* path longer than Lmax: len holds the needed length, path is unspecified */
+    SC_Q_TRUNCATED = 3,    /* path longer than Lmax: len holds the needed length, path is unspecified */
+    SC_Q_RING_OVERFLOW = 4 /* the search's frontier outgrew the device queues twice (16x the usual space on the second
+                            * attempt); no result for this query.  sc_ctx_synchronize enlarges the queues of later calls */
 } sc_query_status;
 
 /* kernels timed by sc_ctx_set_timing (indices for sc_ctx_get_timing) */
@@ -140,10 +142,12 @@ int sc_astar_batch_host(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2
                         int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
 /* Node expansions of the last sc_astar_batch call on this context (synchronises). */
 int sc_astar_last_expansions(sc_ctx* ctx, int64_t* expansions);
-/* Debug: per-query {expansions[Q], then (sub-iterations, kilo-cycles)[Q][2]} of the last
- * sc_astar_batch (the latter only when the environment has SC_ASTAR_DEBUG=1). */
-int sc_astar_debug_stats(sc_ctx* ctx, int32_t* out3, int Q);
-/* Debug/parity: canonical g field (uint32 [H][W], 0xFFFFFFFF = unreached) of ONE query. */
+/* Debug: per-query expansions, popped queue entries, kilo-cycles and steps (int32 [4][Q]) of the last sc_astar_batch
+ * (synchronises).  sc_astar_debug_peek: the launch counters, read without waiting for the stream (bring-up aid). */
+int sc_astar_debug_stats(sc_ctx* ctx, int32_t* stats4, int Q);
+int sc_astar_debug_peek(sc_ctx* ctx, int32_t* out16);
+/* Debug/parity: g field of ONE query (uint32 [H][W]): the optimal cost-to-come g* of every node the search
+ * expanded -- E = {n : g*(n) + h(n) <= C*}, all that paths and parents are read from -- and 0xFFFFFFFF elsewhere. */
 int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
                     int32_t start, int32_t goal, uint32_t* gfield, int32_t* cost, int32_t* status);
 

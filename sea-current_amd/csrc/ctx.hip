@@ -46,7 +46,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     free_scratch(&ctx->colbits); free_scratch(&ctx->edt_flags); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
-    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
+    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->closed); free_scratch(&ctx->actr); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -75,7 +75,19 @@ int sc_stream_wait(sc_ctx* ctx) {
 extern "C" int sc_ctx_synchronize(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    return sc_stream_wait(ctx);
+    int r = sc_stream_wait(ctx);
+    if (r != SC_OK) return r;
+    // A* bucket rings overflowed in some launch since the last synchronisation (the overflowed queries were rerun
+    // with 16x the space on the device): start later launches with larger rings
+    if (ctx->actr.p) {
+        int32_t sticky = 0;
+        SC_HIP(ctx, hipMemcpy(&sticky, (const int32_t*)ctx->actr.p + 4, sizeof(sticky), hipMemcpyDeviceToHost));
+        if (sticky) {
+            SC_HIP(ctx, hipMemset((int32_t*)ctx->actr.p + 4, 0, sizeof(int32_t)));
+            if (ctx->astar_cap < (1 << 22)) ctx->astar_cap *= 4;
+        }
+    }
+    return SC_OK;
 }
 
 int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {
@@ -93,7 +105,8 @@ int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {
 
 extern "C" int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes) {
     if (!ctx || !bytes) return SC_ERR_INVALID;
-    size_t b = ctx->colbits.bytes + ctx->moves.bytes + ctx->gslots.bytes + ctx->buckets.bytes + ctx->qstats.bytes;
+    size_t b = ctx->colbits.bytes + ctx->edt_flags.bytes + ctx->moves.bytes + ctx->gslots.bytes + ctx->closed.bytes + ctx->buckets.bytes +
+               ctx->qstats.bytes + ctx->actr.bytes + ctx->bez_tang.bytes + ctx->bez_gl.bytes + ctx->bez_seginfo.bytes;
     for (auto& s : ctx->staging) b += s.bytes;
     *bytes = (int64_t)b;
     return SC_OK;
@@ -107,13 +120,18 @@ static hipEvent_t get_event(sc_ctx* ctx) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;
     return e;
 }
 
 int sc_time_begin(sc_ctx* ctx, int kid) {
     if (!ctx->timing) return -1;
     sc_ctx::pending_ev p{kid, get_event(ctx), get_event(ctx)};
+    if (!p.a || !p.b) {   // no event to be had: this launch goes untimed
+        if (p.a) ctx->ev_pool.push_back(p.a);
+        if (p.b) ctx->ev_pool.push_back(p.b);
+        return -1;
+    }
     (void)hipEventRecord(p.a, ctx->stream);
     ctx->pending.push_back(p);
     return (int)ctx->pending.size() - 1;
@@ -129,6 +147,7 @@ int sc_time_chain(sc_ctx* ctx, int token, int kid) {
     if (token < 0) return -1;
     (void)hipEventRecord(ctx->pending[token].b, ctx->stream);
     sc_ctx::pending_ev p{kid, ctx->pending[token].b, get_event(ctx)};
+    if (!p.b) return -1;
     p.shared_a = true;
     ctx->pending.push_back(p);
     return (int)ctx->pending.size() - 1;

@@ -31,20 +31,20 @@ struct sc_ctx {
     sc_scratch colbits;     // EDT: uint32 [batch][nb][W]
     sc_scratch edt_flags;   // EDT, rows wider than 1024: int32 [batch], != 0 where the windowed kernel gave a grid up
     sc_scratch moves;       // A*: uint8 [H][W]
-    sc_scratch gslots;      // A*: uint32 [S][cells]
+    sc_scratch gslots;      // A*: uint32 [S][g cells] (4 x 4-cell tiles)
+    sc_scratch closed;      // A*: uint32 [S][bitmap words] closed set, one bit per cell (32 x 16-cell tiles)
     sc_scratch buckets;     // A*: uint32 [S][32][cap]
-    sc_scratch qstats;      // A*: int32 expanded[Q] + flags
+    sc_scratch qstats;      // A*: int32 expanded[Q] | queue order[Q] | overflow list[Q]
+    sc_scratch actr;        // A*: int32 [8] queue / overflow counters of a launch, [4] = sticky overflow flag
     sc_scratch bez_tang;    // Bezier: double [P][n_max][2] tangents
     sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
     sc_scratch bez_seginfo; // resample: int4 [S] (first sample, last sample, spline, segment in spline)
     sc_scratch staging[8];  // _host wrappers
-    int astar_cap = 1 << 15;          // ring entries per bucket (power of two)
+    int astar_cap = 1 << 16;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
     int last_Q = 0;
     int edt_chain_token = -1;       // timing: colbits' end event doubles as band's start event
-    uint32_t astar_epoch = 0;       // descending epoch tag of the g slots (0: slots must be cleared)
-    int astar_shift = 0;            // bits of g below the tag
-    uint32_t astar_last_tag = 0, astar_last_mask = 0xFFFFFFFFu;
+    int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
 };
 
 #define SC_HIP(ctx, call)                                                                  \

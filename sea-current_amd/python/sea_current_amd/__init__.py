@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(NATIVE_DIR, "libsea_current_hip.so")
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
-Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED = 0, 1, 2, 3
+Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED, Q_RING_OVERFLOW = 0, 1, 2, 3, 4
 K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST, K_FMT = range(12)
 
 _lib = None
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "sc_astar_batch_host": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_astar_last_expansions": (_i, [_vp, _i64p]),
     "sc_astar_debug_stats": (_i, [_vp, _vp, _i]),
+    "sc_astar_debug_peek": (_i, [_vp, _vp]),
     "sc_astar_gfield": (_i, [_vp, _vp, _i, _i, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "sc_toppra_hermite_batch": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
     "sc_toppra_hermite_batch_host": (_i, [_vp, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _d, _d] + [_vp] * 5),
@@ -202,9 +203,10 @@ class Context:
         return n.value
 
     def astar_debug_stats(self, Q):
-        out = np.zeros(3 * Q, dtype=np.int32)
+        """Per-query (expansions, popped entries, kilo-cycles, steps) of the last astar_batch (synchronises)."""
+        out = np.zeros((4, Q), dtype=np.int32)
         self._ck(self._l.sc_astar_debug_stats(self._h, _ptr(out), Q), "sc_astar_debug_stats")
-        return out[:Q], out[Q:].reshape(Q, 2)
+        return out[0], out[1], out[2], out[3]
 
     def astar_gfield(self, d2, start, goal, r2=0):
         import torch
