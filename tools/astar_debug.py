@@ -33,7 +33,7 @@ for (W, H, p, Q) in ((40, 28, 0.1, 1), (40, 28, 0.1, 8), (64, 64, 0.25, 64), (25
     dt = time.perf_counter() - t
     print("   synchronised", flush=True)
     o = {k: v.cpu().numpy() for k, v in out.items()}
-    ex = ctx.astar_debug_stats(Q)
+    ex = ctx.astar_debug_stats(Q)[0]
     bad = [q for q in range(Q) if o["status"][q] != ref["status"][q] or o["cost"][q] != ref["cost"][q] or o["len"][q] != ref["len"][q]
            or (ref["status"][q] == 0 and not np.array_equal(o["path"][q, :ref["len"][q]], ref["path"][q, :ref["len"][q]]))]
     print("   %.2f ms; status %s; expansions gpu %d ref %d; mismatching queries: %s" % (dt * 1e3, np.bincount(o["status"], minlength=5).tolist(),
