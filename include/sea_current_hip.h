@@ -207,6 +207,21 @@ int sc_bezier_from_path_batch_host(sc_ctx* ctx, const float* path, const int32_t
 int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_t* seg, const float* t, int M, int order, float* out);
 /* host-pointer form; S = number of segments in ctrl */
 int sc_bezier_eval_batch_host(sc_ctx* ctx, const float* ctrl, int S, const int32_t* seg, const float* t, int M, int order, float* out);
+/* General degree (1 .. SC_BEZIER_MAX_DEGREE): point of segment seg[i] of ctrl viewed as [S][degree+1][2] at parameter
+ * t[i].  Takes over bezier_spline::bezier_curve for any control polygon (:700-763) and, fed with the derivative control
+ * points degree * (P[j+1] - P[j]), ::hodograph (:1041-1053) and the hodograph of a hodograph (::curvature :1017-1039). */
+#define SC_BEZIER_MAX_DEGREE 15
+int sc_bezier_curve_batch(sc_ctx* ctx, const float* ctrl, int degree, const int32_t* seg, const float* t, int M, float* out);
+int sc_bezier_curve_batch_host(sc_ctx* ctx, const float* ctrl, int S, int degree, const int32_t* seg, const float* t, int M, float* out);
+/* The free functions chebfit / chebeval (:1109-1170): B independent least-squares fits y(x) over the Chebyshev columns
+ * T_0 .. T_{degree-1} of x normalised to [-1, 1] by its own range (the reference builds `degree` columns).  Problem b owns
+ * rows off[b] .. off[b+1]-1 of x / y (total = off[B] rows); coef float [B][degree], xrange float [B][2] = (xmin, xmax) --
+ * the three members of the reference's chebpoly.  chebeval evaluates problem b's polynomial at its rows of x. */
+#define SC_CHEB_MAX_DEGREE 32
+int sc_chebfit_batch(sc_ctx* ctx, const float* x, const float* y, const int32_t* off, int B, int total, int degree, float* coef, float* xrange);
+int sc_chebfit_batch_host(sc_ctx* ctx, const float* x, const float* y, const int32_t* off, int B, int degree, float* coef, float* xrange);
+int sc_chebeval_batch(sc_ctx* ctx, const float* x, const int32_t* off, int B, int degree, const float* coef, const float* xrange, float* y);
+int sc_chebeval_batch_host(sc_ctx* ctx, const float* x, const int32_t* off, int B, int degree, const float* coef, const float* xrange, float* y);
 /* bezier_spline::arclength (:767-896): 32-point Gauss-Legendre on nsub (= 1/precision)
  * sub-intervals of every segment.  cum float [S][nsub+1] cumulative length at
  * t = k/nsub, seg_len float [S] (the reference's arclength_data: segments, and

@@ -243,3 +243,28 @@ int sco_bezier_resample(const float* ctrl, int nseg, int nsub, const float* cum,
     free(y);
     return status;
 }
+
+/* ---- public forms of the pieces above, for the free functions of the reference's header ---------------------- */
+/* general degree curve (bezier_curve :700-763): de Casteljau in fp64; ctrl [nseg][deg+1][2] */
+void sco_bezier_curve(const float* ctrl, int deg, const int* seg, const double* t, int m, double* out) {
+    for (int i = 0; i < m; ++i) {
+        double bx[64], by[64];
+        const float* c = ctrl + (size_t)seg[i] * (deg + 1) * 2;
+        for (int j = 0; j <= deg; ++j) { bx[j] = c[2 * j]; by[j] = c[2 * j + 1]; }
+        const double s = t[i], r = 1.0 - s;
+        for (int lvl = 1; lvl <= deg; ++lvl)
+            for (int j = 0; j + lvl <= deg; ++j) { bx[j] = r * bx[j] + s * bx[j + 1]; by[j] = r * by[j] + s * by[j + 1]; }
+        out[2 * i] = bx[0]; out[2 * i + 1] = by[0];
+    }
+}
+/* chebfit / chebeval (:1109-1170) on float abscissae and ordinates; coef [degree] */
+void sco_chebfit(const float* x, const float* y, int m, int degree, double* coef, double* xmin, double* xmax) {
+    double* yd = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+    for (int r = 0; r < m; ++r) yd[r] = y[r];
+    for (int k = 0; k < degree; ++k) coef[k] = 0;
+    chebfit(x, yd, m, degree, coef, xmin, xmax);
+    free(yd);
+}
+void sco_chebeval(const float* x, int m, int degree, const double* coef, double xmin, double xmax, double* y) {
+    for (int r = 0; r < m; ++r) y[r] = chebeval((double)x[r], coef, degree, xmin, xmax);
+}

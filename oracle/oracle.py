@@ -185,6 +185,36 @@ def bezier_resample(ctrl, cum, arclength, profile_pos, nudge=True):
     return dict(status=st, pos=pp, pts=pts, t=tpar, seg=seg, curvature=curv)
 
 
+def bezier_curve(ctrl, seg, t):
+    """general-degree curve; ctrl [nseg, deg+1, 2] -> points [m, 2] (float64)."""
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    seg = np.ascontiguousarray(seg, dtype=np.int32)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    out = np.zeros((t.shape[0], 2))
+    lib().sco_bezier_curve(_p(ctrl, C.c_float), C.c_int(ctrl.shape[1] - 1), _p(seg, C.c_int32), _p(t, C.c_double), C.c_int(t.shape[0]),
+                           _p(out, C.c_double))
+    return out
+
+
+def chebfit(x, y, degree):
+    """free chebfit (sea_current.hpp:1109-1138) -> (coef float64 [degree], xmin, xmax)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    coef = np.zeros(degree)
+    xmin, xmax = C.c_double(), C.c_double()
+    lib().sco_chebfit(_p(x, C.c_float), _p(y, C.c_float), C.c_int(x.shape[0]), C.c_int(degree), _p(coef, C.c_double), C.byref(xmin), C.byref(xmax))
+    return coef, xmin.value, xmax.value
+
+
+def chebeval(x, coef, xmin, xmax):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    y = np.zeros(x.shape[0])
+    lib().sco_chebeval(_p(x, C.c_float), C.c_int(x.shape[0]), C.c_int(coef.shape[0]), _p(coef, C.c_double), C.c_double(xmin), C.c_double(xmax),
+                       _p(y, C.c_double))
+    return y
+
+
 def halton(b, n, state=(0, 0)):
     """next n base-b Halton numbers from state (f, i) -> (float32 [n], new state)."""
     f, i = C.c_int(state[0]), C.c_int(state[1])

@@ -119,6 +119,12 @@ double sco_bezier_arclength(const float* ctrl, int nseg, int nsub, double* cum);
 int sco_bezier_resample(const float* ctrl, int nseg, int nsub, const float* cum, float arclength, float* profile_pos, int n,
                         int nudge, float* pts, float* tpar, int32_t* seg, float* curv);
 
+/* general-degree curve (bezier_curve :700-763; de Casteljau, ctrl [nseg][deg+1][2]) and the free chebfit / chebeval
+ * (:1109-1170: `degree` Chebyshev columns of x normalised by its own range, Householder least squares in fp64) */
+void sco_bezier_curve(const float* ctrl, int deg, const int* seg, const double* t, int m, double* out);
+void sco_chebfit(const float* x, const float* y, int m, int degree, double* coef, double* xmin, double* xmax);
+void sco_chebeval(const float* x, int m, int degree, const double* coef, double xmin, double xmax, double* y);
+
 /* ---- the reference's own planner: FMT* over Halton samples --------------------------------
  * Restates sea_current.hpp:100-132 (halton), :1294-1313 (sample_free), :1328-1337 (near), :1315-1326 + :142-178 (cost),
  * :1339-1407 (fast_marching_trees); see fmt_oracle.c for the tie-break and free-space conventions.  PARITY UNPINNED.

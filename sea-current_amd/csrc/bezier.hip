@@ -16,6 +16,13 @@
 
 struct seg4 { float lx0, ly0, lx1, ly1; };
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+
 __device__ __forceinline__ bool seg_hit(double p1x, double p1y, double p2x, double p2y, const float* l, double* ix, double* iy) {
     const double rx = p2x - p1x, ry = p2y - p1y, sx = (double)l[2] - l[0], sy = (double)l[3] - l[1];
     const double den = rx * sy - ry * sx;
@@ -223,11 +230,6 @@ resample_prepare_kernel(const float* __restrict__ cum, const int32_t* __restrict
     if (lane == 0) status[b] = st;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 // Kernel 2, one workgroup per segment: wave 0 fits the Chebyshev polynomial arclength -> parameter by Householder
 // least squares in fp64 ([T | y] of (nsub+1) x (deg+1) in LDS, rows over lanes), then all threads evaluate the
@@ -323,6 +325,117 @@ resample_eval_kernel(const float* __restrict__ ctrl, const float* __restrict__ c
     }
 }
 
+// ---- general-degree curve (bezier_spline::bezier_curve :700-763, hodograph control points :1041-1053) -------------
+// de Casteljau in fp64 on degree + 1 control points; the reference evaluates the same polynomial through its
+// Bernstein-Fourier form.  Cubics keep bez_eval above (what the recorded run is pinned against).
+__global__ void __launch_bounds__(256)
+bezier_curve_kernel(const float* __restrict__ ctrl, int deg, const int32_t* __restrict__ seg, const float* __restrict__ t, int M,
+                    float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float* c = ctrl + (size_t)seg[i] * (deg + 1) * 2;
+    double bx[SC_BEZIER_MAX_DEGREE + 1], by[SC_BEZIER_MAX_DEGREE + 1];
+#pragma unroll
+    for (int j = 0; j <= SC_BEZIER_MAX_DEGREE; ++j) { bx[j] = j <= deg ? (double)c[2 * j] : 0.0; by[j] = j <= deg ? (double)c[2 * j + 1] : 0.0; }
+    const double s = t[i], r = 1.0 - s;
+#pragma unroll
+    for (int lvl = 1; lvl <= SC_BEZIER_MAX_DEGREE; ++lvl)
+#pragma unroll
+        for (int j = 0; j + lvl <= SC_BEZIER_MAX_DEGREE; ++j)
+            if (lvl <= deg && j + lvl <= deg) { bx[j] = r * bx[j] + s * bx[j + 1]; by[j] = r * by[j] + s * by[j + 1]; }
+    out[2 * i] = (float)bx[0]; out[2 * i + 1] = (float)by[0];
+}
+
+// ---- free chebfit / chebeval (sea_current.hpp:1109-1170) ------------------------------------------------------
+// Least squares over the columns T_0 .. T_{degree-1} of the abscissa normalised to [-1, 1] (the reference builds
+// `degree` columns, :1122-1128), by Householder reflections in fp64 (Eigen's HouseholderQR in float32 there).  One
+// workgroup per problem; [T | y] lives in global scratch (a problem may have tens of thousands of rows:
+// examples/test.cpp:168 fits 20 002 curve points), column operations are block reductions.
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+cheb_fit_kernel(const float* __restrict__ x, const float* __restrict__ y, const int32_t* __restrict__ off, int degree, double* __restrict__ Aall,
+                float* __restrict__ coef_out, float* __restrict__ xrange) {
+    __shared__ double red[4];
+    __shared__ double coef[SC_CHEB_MAX_DEGREE];
+    __shared__ float mm[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int r0 = off[b], m = off[b + 1] - r0, nc = degree + 1;
+    double* A = Aall + (size_t)r0 * nc;
+    const float* xb = x + r0;
+    const float* yb = y + r0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = tid; r < m; r += 256) { mn = fminf(mn, xb[r]); mx = fmaxf(mx, xb[r]); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((tid & 63) == 0) { mm[0][tid >> 6] = mn; mm[1][tid >> 6] = mx; }
+    __syncthreads();
+    const double xmin = fminf(fminf(mm[0][0], mm[0][1]), fminf(mm[0][2], mm[0][3]));
+    const double xmax = fmaxf(fmaxf(mm[1][0], mm[1][1]), fmaxf(mm[1][2], mm[1][3]));
+    for (int r = tid; r < m; r += 256) {
+        const double xn = (2 * (double)xb[r] - (xmax + xmin)) / (xmax - xmin);
+        double* a = A + (size_t)r * nc;
+        a[0] = 1;
+        if (degree > 1) a[1] = xn;
+        for (int j = 2; j < degree; ++j) a[j] = 2 * xn * a[j - 1] - a[j - 2];
+        a[degree] = yb[r];
+    }
+    __syncthreads();
+    for (int k = 0; k < degree && k < m; ++k) {
+        double part = 0;
+        for (int r = k + tid; r < m; r += 256) part += A[(size_t)r * nc + k] * A[(size_t)r * nc + k];
+        const double n2 = block_sum256(part, red), nrm = sqrt(n2);
+        if (nrm == 0) continue;
+        const double akk = A[(size_t)k * nc + k], alpha = akk > 0 ? -nrm : nrm;
+        const double vk = akk - alpha, vtv = nrm * nrm - akk * akk + vk * vk;
+        __syncthreads();                      // everyone has read a_kk before column k's head is touched
+        for (int j = k + 1; j < nc; ++j) {
+            double dpart = 0;
+            for (int r = k + 1 + tid; r < m; r += 256) dpart += A[(size_t)r * nc + k] * A[(size_t)r * nc + j];
+            const double dd = block_sum256(dpart, red) + vk * A[(size_t)k * nc + j];
+            const double f = 2 * dd / vtv;
+            __syncthreads();
+            for (int r = k + 1 + tid; r < m; r += 256) A[(size_t)r * nc + j] -= f * A[(size_t)r * nc + k];
+            if (tid == 0) A[(size_t)k * nc + j] -= f * vk;
+            __syncthreads();
+        }
+        if (tid == 0) A[(size_t)k * nc + k] = alpha;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int k = degree - 1; k >= 0; --k) {
+            double v = k < m ? A[(size_t)k * nc + degree] : 0.0;
+            for (int j = k + 1; j < degree; ++j) v -= (k < m ? A[(size_t)k * nc + j] : 0.0) * coef[j];
+            const double dg = k < m ? A[(size_t)k * nc + k] : 0.0;
+            coef[k] = dg != 0 ? v / dg : 0.0;   // rank-deficient column (the reference asserts full rank in DEBUG, :1134)
+        }
+        for (int k = 0; k < degree; ++k) coef_out[(size_t)b * degree + k] = (float)coef[k];
+        xrange[2 * b] = (float)xmin; xrange[2 * b + 1] = (float)xmax;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cheb_eval_kernel(const float* __restrict__ x, const int32_t* __restrict__ off, int degree, const float* __restrict__ coef,
+                 const float* __restrict__ xrange, float* __restrict__ y) {
+    const int b = blockIdx.x;
+    const int r0 = off[b], m = off[b + 1] - r0;
+    const double xmin = xrange[2 * b], xmax = xrange[2 * b + 1];
+    const float* c = coef + (size_t)b * degree;
+    for (int r = threadIdx.x; r < m; r += 256) {
+        const double xn = (2 * (double)x[r0 + r] - (xmax + xmin)) / (xmax - xmin);
+        double t0 = 1, t1 = xn, v = c[0];
+        if (degree > 1) v += (double)c[1] * t1;
+        for (int j = 2; j < degree; ++j) { const double t2 = 2 * xn * t1 - t0; v += (double)c[j] * t2; t0 = t1; t1 = t2; }
+        y[r0 + r] = (float)v;
+    }
+}
+
 static void gl32_host(double* x, double* w) {
     const int N = 32;
     for (int i = 0; i < N; ++i) {
@@ -361,6 +474,40 @@ extern "C" int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_
     SC_HIP(ctx, hipSetDevice(ctx->device));
     int tk = sc_time_begin(ctx, SC_K_BEZIER);
     hipLaunchKernelGGL(bezier_eval_kernel, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctrl, seg, t, M, order, out);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_bezier_curve_batch(sc_ctx* ctx, const float* ctrl, int degree, const int32_t* seg, const float* t, int M, float* out) {
+    if (!ctx || !ctrl || !seg || !t || !out || M <= 0 || degree < 1 || degree > SC_BEZIER_MAX_DEGREE) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int tk = sc_time_begin(ctx, SC_K_BEZIER);
+    hipLaunchKernelGGL(bezier_curve_kernel, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, ctrl, degree, seg, t, M, out);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_chebfit_batch(sc_ctx* ctx, const float* x, const float* y, const int32_t* off, int B, int total, int degree, float* coef,
+                                float* xrange) {
+    if (!ctx || !x || !y || !off || !coef || !xrange || B <= 0 || total <= 0 || degree < 1 || degree > SC_CHEB_MAX_DEGREE) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int r = sc_scratch_reserve(ctx, &ctx->cheb_a, (size_t)total * (degree + 1) * sizeof(double));
+    if (r != SC_OK) return r;
+    int tk = sc_time_begin(ctx, SC_K_RESAMPLE);
+    hipLaunchKernelGGL(cheb_fit_kernel, dim3(B), dim3(256), 0, ctx->stream, x, y, off, degree, (double*)ctx->cheb_a.p, coef, xrange);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_chebeval_batch(sc_ctx* ctx, const float* x, const int32_t* off, int B, int degree, const float* coef, const float* xrange,
+                                 float* y) {
+    if (!ctx || !x || !off || !coef || !xrange || !y || B <= 0 || degree < 1 || degree > SC_CHEB_MAX_DEGREE) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int tk = sc_time_begin(ctx, SC_K_RESAMPLE);
+    hipLaunchKernelGGL(cheb_eval_kernel, dim3(B), dim3(256), 0, ctx->stream, x, off, degree, coef, xrange, y);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -46,7 +46,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     free_scratch(&ctx->colbits); free_scratch(&ctx->edt_flags); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
-    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->closed); free_scratch(&ctx->actr); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo);
+    free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->closed); free_scratch(&ctx->actr); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo); free_scratch(&ctx->cheb_a);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -106,7 +106,7 @@ int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {
 extern "C" int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes) {
     if (!ctx || !bytes) return SC_ERR_INVALID;
     size_t b = ctx->colbits.bytes + ctx->edt_flags.bytes + ctx->moves.bytes + ctx->gslots.bytes + ctx->closed.bytes + ctx->buckets.bytes +
-               ctx->qstats.bytes + ctx->actr.bytes + ctx->bez_tang.bytes + ctx->bez_gl.bytes + ctx->bez_seginfo.bytes;
+               ctx->qstats.bytes + ctx->actr.bytes + ctx->bez_tang.bytes + ctx->bez_gl.bytes + ctx->bez_seginfo.bytes + ctx->cheb_a.bytes;
     for (auto& s : ctx->staging) b += s.bytes;
     *bytes = (int64_t)b;
     return SC_OK;
@@ -404,5 +404,64 @@ extern "C" int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, 
     SC_HIP(ctx, hipMemcpyAsync(len, b + o_len, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(cost, b + o_c, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(status, b + o_status, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_bezier_curve_batch_host(sc_ctx* ctx, const float* ctrl, int S, int degree, const int32_t* seg, const float* t, int M, float* out) {
+    if (!ctx || !ctrl || !seg || !t || !out || S <= 0 || M <= 0 || degree < 1 || degree > SC_BEZIER_MAX_DEGREE) return SC_ERR_INVALID;
+    for (int i = 0; i < M; ++i)
+        if (seg[i] < 0 || seg[i] >= S) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cbytes = (size_t)S * (degree + 1) * 8;
+    const size_t cb = (cbytes + 255) & ~(size_t)255, mb = ((size_t)M * 4 + 255) & ~(size_t)255;
+    STAGE(5, cb + 2 * mb + (size_t)M * 8);
+    char* b = (char*)ctx->staging[5].p;
+    SC_HIP(ctx, hipMemcpyAsync(b, ctrl, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + cb, seg, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + cb + mb, t, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_curve_batch(ctx, (const float*)b, degree, (const int32_t*)(b + cb), (const float*)(b + cb + mb), M, (float*)(b + cb + 2 * mb));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(out, b + cb + 2 * mb, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_chebfit_batch_host(sc_ctx* ctx, const float* x, const float* y, const int32_t* off, int B, int degree, float* coef, float* xrange) {
+    if (!ctx || !x || !y || !off || !coef || !xrange || B <= 0 || degree < 1 || degree > SC_CHEB_MAX_DEGREE || off[0] != 0 || off[B] <= 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)off[B];
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_x = 0, o_y = al(n * 4), o_off = o_y + al(n * 4), o_c = o_off + al((size_t)(B + 1) * 4), o_r = o_c + al((size_t)B * degree * 4),
+                 total = o_r + al((size_t)B * 8);
+    STAGE(6, total);
+    char* b = (char*)ctx->staging[6].p;
+    SC_HIP(ctx, hipMemcpyAsync(b + o_x, x, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_y, y, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_off, off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_chebfit_batch(ctx, (const float*)(b + o_x), (const float*)(b + o_y), (const int32_t*)(b + o_off), B, (int)n, degree, (float*)(b + o_c),
+                             (float*)(b + o_r));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(coef, b + o_c, (size_t)B * degree * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(xrange, b + o_r, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
+extern "C" int sc_chebeval_batch_host(sc_ctx* ctx, const float* x, const int32_t* off, int B, int degree, const float* coef, const float* xrange,
+                                      float* y) {
+    if (!ctx || !x || !off || !coef || !xrange || !y || B <= 0 || degree < 1 || degree > SC_CHEB_MAX_DEGREE || off[0] != 0 || off[B] <= 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)off[B];
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_x = 0, o_y = al(n * 4), o_off = o_y + al(n * 4), o_c = o_off + al((size_t)(B + 1) * 4), o_r = o_c + al((size_t)B * degree * 4),
+                 total = o_r + al((size_t)B * 8);
+    STAGE(6, total);
+    char* b = (char*)ctx->staging[6].p;
+    SC_HIP(ctx, hipMemcpyAsync(b + o_x, x, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_off, off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_c, coef, (size_t)B * degree * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + o_r, xrange, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_chebeval_batch(ctx, (const float*)(b + o_x), (const int32_t*)(b + o_off), B, degree, (const float*)(b + o_c), (const float*)(b + o_r),
+                              (float*)(b + o_y));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(y, b + o_y, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     return sc_ctx_synchronize(ctx);
 }

@@ -39,6 +39,7 @@ struct sc_ctx {
     sc_scratch bez_tang;    // Bezier: double [P][n_max][2] tangents
     sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
     sc_scratch bez_seginfo; // resample: int4 [S] (first sample, last sample, spline, segment in spline)
+    sc_scratch cheb_a;      // chebfit: double [rows][degree + 1], the [T | y] matrices of a batch
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 16;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed

@@ -71,6 +71,12 @@ _SIGNATURES = {
     "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_eval_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sc_bezier_eval_batch_host": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "sc_bezier_curve_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "sc_bezier_curve_batch_host": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "sc_chebfit_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sc_chebfit_batch_host": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sc_chebeval_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sc_chebeval_batch_host": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sc_bezier_arclength_batch_host": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "sc_bezier_arclength_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "sc_bezier_resample_batch": (_i, [_vp] * 5 + [_i, _i, _i, _vp, _vp, _i] + [_vp] * 5),
@@ -301,6 +307,30 @@ class Context:
         out = torch.empty((M, 2), dtype=torch.float32, device=t.device)
         self._ck(self._l.sc_bezier_eval_batch(self._h, _ptr(ctrl), _ptr(seg), _ptr(t), M, order, _ptr(out)), "sc_bezier_eval_batch")
         return out
+
+    def bezier_curve(self, ctrl, seg, t):
+        """General degree: ctrl float32 [S, degree+1, 2] (GPU), seg int32 [M], t float32 [M] -> points float32 [M, 2]."""
+        import torch
+        M = t.shape[0]
+        out = torch.empty((M, 2), dtype=torch.float32, device=t.device)
+        self._ck(self._l.sc_bezier_curve_batch(self._h, _ptr(ctrl), ctrl.shape[1] - 1, _ptr(seg), _ptr(t), M, _ptr(out)), "sc_bezier_curve_batch")
+        return out
+
+    def chebfit(self, x, y, off, degree):
+        """B least-squares Chebyshev fits; x, y float32 [total], off int32 [B+1] (all GPU) -> (coef [B, degree], xrange [B, 2])."""
+        import torch
+        B = off.shape[0] - 1
+        coef = torch.empty((B, degree), dtype=torch.float32, device=x.device)
+        xr = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+        self._ck(self._l.sc_chebfit_batch(self._h, _ptr(x), _ptr(y), _ptr(off), B, x.shape[0], degree, _ptr(coef), _ptr(xr)), "sc_chebfit_batch")
+        return coef, xr
+
+    def chebeval(self, x, off, coef, xr):
+        import torch
+        B, degree = coef.shape
+        y = torch.empty_like(x)
+        self._ck(self._l.sc_chebeval_batch(self._h, _ptr(x), _ptr(off), B, degree, _ptr(coef), _ptr(xr), _ptr(y)), "sc_chebeval_batch")
+        return y
 
     def bezier_arclength(self, ctrl, nsub=100):
         """ctrl float32 [...,4,2] (GPU) -> (cum float32 [S,nsub+1], seg_len float32 [S])."""

@@ -26,10 +26,10 @@
 // all functions are `inline` (the reference defines non-inline functions in a header).
 // Also mirrored from the "next" rows: bezier_spline::from_path, ::arclength, ::resample,
 // ::curvature, ::angular_velocity -- with these the reference's whole example pipeline (examples/zmq_test.cpp:66-93)
-// runs through this header.  bezier_spline::pts is a std::vector<Vector2f> (the reference: Matrix<float,Dynamic,2>).
+// runs through this header.  bezier_spline::pts is an n x 2 matrix (Eigen's when present) as in the reference (:390).
 // The planner's sampling helpers keep their signatures as host functions (halton, sample_free, near, point_set,
-// x_state / y_state); fast_marching_trees itself plans on the grid.  Not mirrored: the 10001-point display sampling of
-// from_path, the ZMQ transport.  The service's request text and JSON reply are parse_path_request / serialize_path_to_json.
+// x_state / y_state); fast_marching_trees itself plans on the grid.  Not mirrored: Q_cache (the reference's cached
+// Fourier coefficients), the ZMQ transport.  The service's request text and JSON reply are parse_path_request / serialize_path_to_json.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -48,6 +48,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <unordered_set>
 #include <vector>
 
@@ -74,8 +75,9 @@ using Eigen::Vector2f;
 using Eigen::VectorXf;
 using VectorXd = Eigen::VectorXd;
 template <int N> using VectorNd = Eigen::Matrix<double, N, 1>;
+using points_matrix = Eigen::Matrix<float, Eigen::Dynamic, 2>;   // bezier_spline::pts (sea_current.hpp:390)
 #else
-// minimal stand-ins with the accessors the API uses
+// minimal stand-ins with the accessors the API and the reference's call sites use
 struct Vector2f {
     float v[2] = {0, 0};
     Vector2f() = default;
@@ -84,41 +86,102 @@ struct Vector2f {
     float y() const { return v[1]; }
     float& x() { return v[0]; }
     float& y() { return v[1]; }
+    float operator()(int i) const { return v[i]; }
+    float& operator()(int i) { return v[i]; }
     Vector2f operator+(const Vector2f& o) const { return {v[0] + o.v[0], v[1] + o.v[1]}; }
     Vector2f operator-(const Vector2f& o) const { return {v[0] - o.v[0], v[1] - o.v[1]}; }
+    Vector2f operator-() const { return {-v[0], -v[1]}; }
     Vector2f operator*(float s) const { return {v[0] * s, v[1] * s}; }
+    Vector2f operator/(float s) const { return {v[0] / s, v[1] / s}; }
     bool operator==(const Vector2f& o) const { return v[0] == o.v[0] && v[1] == o.v[1]; }
+    float dot(const Vector2f& o) const { return v[0] * o.v[0] + v[1] * o.v[1]; }
     float norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1]); }
+    Vector2f normalized() const { const float n = norm(); return n > 0 ? Vector2f(v[0] / n, v[1] / n) : *this; }
 };
+template <class S, class = std::enable_if_t<std::is_arithmetic_v<S>>>
+inline Vector2f operator*(S s, const Vector2f& a) { return a * (float)s; }
+// dynamic column vector: `Vec v{n}` / `Vec v(n)` give n elements (as Eigen's size constructor does), v(i), v(i, 0), v[i]
 template <class T> struct VectorX_ {
     std::vector<T> d;
     VectorX_() = default;
     explicit VectorX_(size_t n) : d(n) {}
     static VectorX_ Zero(size_t n) { return VectorX_(n); }
+    static VectorX_ Ones(size_t n) { VectorX_ v(n); std::fill(v.d.begin(), v.d.end(), T(1)); return v; }
     size_t rows() const { return d.size(); }
+    size_t cols() const { return 1; }
     size_t size() const { return d.size(); }
     T& operator()(size_t i) { return d[i]; }
     const T& operator()(size_t i) const { return d[i]; }
+    T& operator()(size_t i, size_t) { return d[i]; }
+    const T& operator()(size_t i, size_t) const { return d[i]; }
     T& operator[](size_t i) { return d[i]; }
     const T& operator[](size_t i) const { return d[i]; }
     T* data() { return d.data(); }
     const T* data() const { return d.data(); }
+    auto begin() { return d.begin(); }
+    auto end() { return d.end(); }
+    auto begin() const { return d.begin(); }
+    auto end() const { return d.end(); }
+    T minCoeff() const { return *std::min_element(d.begin(), d.end()); }
+    T maxCoeff() const { return *std::max_element(d.begin(), d.end()); }
 };
 using VectorXf = VectorX_<float>;
 using VectorXd = VectorX_<double>;
-template <int N> struct VectorNd {
-    double d[N] = {};
-    VectorNd() = default;
-    VectorNd(std::initializer_list<double> l) { int i = 0; for (double x : l) if (i < N) d[i++] = x; }
+// fixed-size column vector: `Vec<1> v{x}` lists the coefficients
+template <class T, int N> struct VectorN_ {
+    T d[N] = {};
+    VectorN_() = default;
+    VectorN_(std::initializer_list<T> l) { int i = 0; for (T x : l) if (i < N) d[i++] = x; }
     int rows() const { return N; }
-    double& operator()(int i) { return d[i]; }
-    const double& operator()(int i) const { return d[i]; }
-    double& operator[](int i) { return d[i]; }
-    const double& operator[](int i) const { return d[i]; }
+    T& operator()(int i) { return d[i]; }
+    const T& operator()(int i) const { return d[i]; }
+    T& operator()(int i, int) { return d[i]; }
+    const T& operator()(int i, int) const { return d[i]; }
+    T& operator[](int i) { return d[i]; }
+    const T& operator[](int i) const { return d[i]; }
+};
+template <int N> using VectorNd = VectorN_<double, N>;
+// n x 2 matrix of points, row-major: m(i, c), m.rows(), m.col(c) (a copy), m.row(i)
+struct points_matrix {
+    std::vector<float> d;
+    points_matrix() = default;
+    explicit points_matrix(size_t n, size_t = 2) : d(2 * n) {}
+    static points_matrix Zero(size_t n, size_t = 2) { return points_matrix(n); }
+    void resize(size_t n, size_t = 2) { d.resize(2 * n); }
+    size_t rows() const { return d.size() / 2; }
+    size_t cols() const { return 2; }
+    float& operator()(size_t i, size_t c) { return d[2 * i + c]; }
+    const float& operator()(size_t i, size_t c) const { return d[2 * i + c]; }
+    Vector2f row(size_t i) const { return Vector2f(d[2 * i], d[2 * i + 1]); }
+    VectorXf col(size_t c) const { VectorXf v(rows()); for (size_t i = 0; i < rows(); ++i) v(i) = d[2 * i + c]; return v; }
+    const float* data() const { return d.data(); }
+    float* data() { return d.data(); }
 };
 #endif
 
-// stand-ins for the toppra types that appear in the reference's signatures
+}  // namespace turtle::sc
+
+// The names the reference's callers spell (examples/zmq_test.cpp:69-86, examples/test.cpp:184-204, examples/json_test.cpp:
+// 29-47): toppra::Vector / toppra::value_type, and Eigen::Vector<value_type, N> for the arguments of gen_vel_prof.  With
+// toppra / Eigen on the include path they are the real types; otherwise these aliases of the stand-ins above keep
+// those call sites compiling unchanged (define SC_NO_NAMESPACE_STANDINS to keep namespaces `toppra` / `Eigen` untouched).
+#if __has_include(<toppra/toppra.hpp>)
+#include <toppra/toppra.hpp>
+#elif !defined(SC_NO_NAMESPACE_STANDINS)
+namespace toppra {
+using value_type = double;
+using Vector = turtle::sc::VectorXd;
+}  // namespace toppra
+#endif
+#if !defined(SC_HAVE_EIGEN) && !defined(SC_NO_NAMESPACE_STANDINS)
+namespace Eigen {
+template <class T, int N> using Vector = turtle::sc::VectorN_<T, N>;
+}  // namespace Eigen
+#endif
+
+namespace turtle::sc {
+
+// the toppra types that appear in the reference's signatures (`using toppra::value_type`, sea_current.hpp:1172)
 using value_type = double;
 namespace toppra_compat { using Vector = VectorXd; }
 
@@ -162,7 +225,17 @@ struct bounding_rect {
     }
 };
 
-inline float pt_dist(const Vector2f& u, const Vector2f& v = {0, 0}) { return std::hypot(v.x() - u.x(), v.y() - u.y()); }
+// L2 distance, in the reference's arithmetic (:86-88): float differences, squared and rooted in double -- the GPU planner
+// (csrc/fmt.hip) and this host function then agree to the bit on the radius tests of near()
+inline float pt_dist(const Vector2f& u, const Vector2f& v = {0, 0}) {
+    const double dx = v.x() - u.x(), dy = v.y() - u.y();
+    return (float)std::sqrt(dx * dx + dy * dy);
+}
+// distance from point a to the (infinite) line through p1 and p2 (:181-190)
+inline float dist_pt_line(const Vector2f& p1, const Vector2f& p2, const Vector2f a) {
+    const float twice_area = std::abs((p2.x() - p1.x()) * (p1.y() - a.y()) - (p1.x() - a.x()) * (p2.y() - p1.y()));
+    return twice_area / (p2 - p1).norm();
+}
 inline float cross2d(const Vector2f& a, const Vector2f& b) { return a.x() * b.y() - a.y() * b.x(); }
 
 // proper intersection of segments p1p2 and q1q2 (colinear overlap counts as no hit, as in :142-178)
@@ -484,29 +557,150 @@ public:
     }
 };
 
-// ---- path smoothing (sea_current.hpp:321-326, 388-431, 599-683, 767-896) ---------------------------
+// ---- path smoothing (sea_current.hpp:321-431, 522-1170) ---------------------------------------------
 struct arclength_data {
     float arclength = 0;
     std::vector<VectorXf> segments;   // cumulative arclength of each segment at t = k * precision
     std::vector<VectorXf> positions;  // the parameters t of those table entries
 };
 
+// Chebyshev polynomial: coefficients of T_0 .. T_{degree-1} on [xmin, xmax] (:328-335)
+struct chebpoly {
+    VectorXf coeffs;
+    float xmin;
+    float xmax;
+    chebpoly(VectorXf coeffs, const float xmin, const float xmax) : coeffs(std::move(coeffs)), xmin(xmin), xmax(xmax) {}
+};
+
+// Least-squares fit of y(x) by `degree` Chebyshev columns (:1109-1138; Householder least squares on the GPU,
+// sc_chebfit_batch) and its evaluation (:1140-1170, sc_chebeval_batch).
+inline chebpoly chebfit(const VectorXf& x, const VectorXf& y, const int degree, gpu_context& ctx = default_context()) {
+    SC_ASSERT(degree >= 1, "degree must be a positive integer");
+    SC_ASSERT(x.rows() == y.rows(), "x and y must have the same number of rows");
+    const int m = (int)x.rows();
+    SC_ASSERT(m > 0 && std::abs(x.maxCoeff() - x.minCoeff()) > 0.00001, "Error: vector x should not have all equal values");
+    std::vector<float> xs(m), ys(m), coef(degree);
+    for (int i = 0; i < m; ++i) { xs[i] = x(i); ys[i] = y(i); }
+    const int32_t off[2] = {0, m};
+    float xr[2] = {0, 0};
+    ctx.check(sc_chebfit_batch_host(ctx.get(), xs.data(), ys.data(), off, 1, degree, coef.data(), xr), "sc_chebfit_batch_host");
+    VectorXf c = VectorXf::Zero(degree);
+    for (int k = 0; k < degree; ++k) c(k) = coef[k];
+    return chebpoly(std::move(c), xr[0], xr[1]);
+}
+inline VectorXf chebeval(const VectorXf& x, const chebpoly& b, const int degree, gpu_context& ctx = default_context()) {
+    SC_ASSERT(degree >= 1 && (int)b.coeffs.rows() >= degree, "degree must be a positive integer within the polynomial");
+    const int m = (int)x.rows();
+    VectorXf y = VectorXf::Zero(m);
+    if (m == 0) return y;
+    std::vector<float> xs(m), ys(m), coef(degree);
+    for (int i = 0; i < m; ++i) xs[i] = x(i);
+    for (int k = 0; k < degree; ++k) coef[k] = b.coeffs(k);
+    const int32_t off[2] = {0, m};
+    const float xr[2] = {b.xmin, b.xmax};
+    ctx.check(sc_chebeval_batch_host(ctx.get(), xs.data(), off, 1, degree, coef.data(), xr, ys.data()), "sc_chebeval_batch_host");
+    for (int i = 0; i < m; ++i) y(i) = ys[i];
+    return y;
+}
+
+// Tangent heuristics of Lau, Sprunk, Burgard (IROS 2009) as the reference states them (:339-377): scalar host
+// helpers for callers that build control points by hand (examples/test.cpp:88-104); from_path computes the same on the GPU.
+inline float tangent_magnitude(const Vector2f& W_0, const Vector2f& W_1, const Vector2f& W_2) {
+    return 0.5f * std::min(pt_dist(W_0, W_1), pt_dist(W_1, W_2));
+}
+// tangent at W_1: perpendicular to the bisector of the angle W_0 W_1 W_2, pointing on towards W_2
+inline Vector2f calc_tangent(const Vector2f& W_0, const Vector2f& W_1, const Vector2f& W_2) {
+    const Vector2f u = W_0 - W_1, v = W_2 - W_1;
+    const float half = std::acos(u.dot(v) / (pt_dist(u) * pt_dist(v))) / 2;
+    const float a_u = std::atan2(u.y(), u.x()), a_v = std::atan2(v.y(), v.x());
+    const float ang = a_u + (a_v - a_u < 0 ? -half : half);
+    Vector2f l90 = Vector2f(std::sin(ang), -std::cos(ang)).normalized();
+    const float sign = pt_dist(W_1 + l90, W_2) < pt_dist(W_1 + (-l90), W_2) ? 1.0f : -1.0f;
+    return tangent_magnitude(W_0, W_1, W_2) * (sign * l90);
+}
+inline Vector2f calc_start_tangent(const Vector2f& W_0, const Vector2f& W_1, const float theta) {
+    return tangent_magnitude(W_0, W_1, W_0) * Vector2f(std::cos(theta), std::sin(theta));
+}
+inline Vector2f calc_end_tangent(const Vector2f& W_1, const Vector2f W_2) {
+    return tangent_magnitude(W_1, W_2, W_1) * (W_2 - W_1).normalized();
+}
+
 struct velocity_profile;
 
 class bezier_spline {
 public:
-    std::vector<std::vector<Vector2f>> ctrl_pts;  // 4 control points per leg
-    std::vector<Vector2f> pts;                    // sampled points (filled by resample), in sample order
+    std::vector<std::vector<Vector2f>> ctrl_pts;  // control points per segment (degree + 1 each)
+    points_matrix pts;                            // sampled points, one row each, in sample order
     std::vector<VectorXf> positions;              // per segment: the curve parameters of its samples (as :392)
+    // (the reference also caches the Fourier coefficients of its Bernstein-Fourier evaluation, Q_cache :393; curves are
+    // evaluated from the control points here, so there is nothing to cache)
 
     bezier_spline() = default;
+    bezier_spline(const std::vector<std::vector<Vector2f>>& ctrl_pts, const points_matrix& pts, const std::vector<VectorXf>& positions)
+        : ctrl_pts(ctrl_pts), pts(pts), positions(positions) {}
     int n_segments() const { return (int)ctrl_pts.size(); }
-    int n_pts() const { return (int)pts.size(); }
+    int n_pts() const { return (int)pts.rows(); }
     int degree() const { return ctrl_pts.empty() ? 0 : (int)ctrl_pts[0].size() - 1; }
 
-    // cubic Bezier spline through a piecewise-linear path; tangents by the Lau09 heuristics, shrunk
-    // against the obstacle edges of `ps` (same signature as :599; the tangents and control points are
-    // computed on the GPU, sc_bezier_from_path_batch)
+    // points of segments[i] (all of one degree) at parameters t[i], on the GPU: cubics through sc_bezier_eval_batch (the
+    // arithmetic pinned to the recorded run), any other degree through sc_bezier_curve_batch
+    static points_matrix evaluate(const std::vector<std::vector<Vector2f>>& cps, const std::vector<int32_t>& seg, const std::vector<float>& t,
+                                  gpu_context& ctx = default_context()) {
+        const int S = (int)cps.size(), M = (int)t.size(), deg = S ? (int)cps[0].size() - 1 : 0;
+        points_matrix out(M, 2);
+        if (M == 0) return out;
+        SC_ASSERT(deg >= 1 && deg <= SC_BEZIER_MAX_DEGREE, "ctrl_pts must have at least 2 points");
+        std::vector<float> c((size_t)S * (deg + 1) * 2), xy(2 * (size_t)M);
+        for (int i = 0; i < S; ++i)
+            for (int k = 0; k <= deg; ++k) { c[((size_t)i * (deg + 1) + k) * 2] = cps[i][k].x(); c[((size_t)i * (deg + 1) + k) * 2 + 1] = cps[i][k].y(); }
+        if (deg == 3) ctx.check(sc_bezier_eval_batch_host(ctx.get(), c.data(), S, seg.data(), t.data(), M, 0, xy.data()), "sc_bezier_eval_batch_host");
+        else ctx.check(sc_bezier_curve_batch_host(ctx.get(), c.data(), S, deg, seg.data(), t.data(), M, xy.data()), "sc_bezier_curve_batch_host");
+        for (int i = 0; i < M; ++i) { out(i, 0) = xy[2 * i]; out(i, 1) = xy[2 * i + 1]; }
+        return out;
+    }
+
+    // one curve from its control polygon, sampled at `positions` in [0, 1] (:684-752)
+    static bezier_spline bezier_curve(const std::vector<Vector2f>& ctrl_pts, const VectorXf& positions, gpu_context& ctx = default_context()) {
+        SC_ASSERT(ctrl_pts.size() >= 2, "ctrl_pts must have at least 2 points");
+        const int M = (int)positions.rows();
+        std::vector<float> t(M);
+        for (int i = 0; i < M; ++i) t[i] = positions(i);
+        return bezier_spline({ctrl_pts}, evaluate({ctrl_pts}, std::vector<int32_t>(M, 0), t, ctx), {positions});
+    }
+    static bezier_spline bezier_curve(const std::vector<Vector2f>& ctrl_pts, const std::vector<float>& positions, gpu_context& ctx = default_context()) {
+        VectorXf p = VectorXf::Zero(positions.size());
+        for (size_t i = 0; i < positions.size(); ++i) p(i) = positions[i];
+        return bezier_curve(ctrl_pts, p, ctx);
+    }
+    // ... sampled at k * precision, k = 0 .. 1/precision (:754-763)
+    static bezier_spline bezier_curve(const std::vector<Vector2f>& ctrl_pts, const float precision, gpu_context& ctx = default_context()) {
+        SC_ASSERT(precision < 1 && precision > 0, "spline percision must be in (0, 1)");
+        const int n = (int)std::lround(1.0f / precision);
+        VectorXf p = VectorXf::Zero(n + 1);
+        for (int i = 0; i <= n; ++i) p(i) = std::max(0.0f, std::min(i * precision, 1.0f));
+        return bezier_curve(ctrl_pts, p, ctx);
+    }
+
+    // the segments, sample positions and points of several splines, one after the other (:543-570)
+    static bezier_spline join_splines(const std::vector<bezier_spline>& splines) {
+        bezier_spline bs;
+        size_t n = 0;
+        for (const auto& sp : splines) n += (size_t)sp.n_pts();
+        bs.pts = points_matrix::Zero(n, 2);
+        size_t o = 0;
+        for (const auto& sp : splines) {
+            for (int i = 0; i < sp.n_segments(); ++i) {
+                bs.ctrl_pts.push_back(sp.ctrl_pts[i]);
+                if (i < (int)sp.positions.size()) bs.positions.push_back(sp.positions[i]);
+            }
+            for (int r = 0; r < sp.n_pts(); ++r, ++o) { bs.pts(o, 0) = sp.pts(r, 0); bs.pts(o, 1) = sp.pts(r, 1); }
+        }
+        return bs;
+    }
+
+    // cubic Bezier spline through a piecewise-linear path; tangents by the Lau09 heuristics, shrunk against the
+    // obstacle edges of `ps` (same signature as :599; tangents and control points on the GPU,
+    // sc_bezier_from_path_batch), every leg sampled at 1e-4 like the reference's (:679)
     static bezier_spline from_path(const std::vector<Vector2f>& path, const planning_space& ps, float start_angle = NAN,
                                    gpu_context& ctx = default_context()) {
         SC_ASSERT(path.size() >= 2, "Not enough points for a path");
@@ -523,6 +717,15 @@ public:
         bs.ctrl_pts.resize(n - 1);
         for (int i = 0; i < n - 1; ++i)
             for (int k = 0; k < 4; ++k) bs.ctrl_pts[i].push_back(Vector2f(c[8 * i + 2 * k], c[8 * i + 2 * k + 1]));
+        constexpr int NS = 10000;   // 1 / 1e-4
+        VectorXf p = VectorXf::Zero(NS + 1);
+        for (int k = 0; k <= NS; ++k) p(k) = std::min(k * 1e-4f, 1.0f);
+        std::vector<int32_t> seg((size_t)(n - 1) * (NS + 1));
+        std::vector<float> t(seg.size());
+        for (int i = 0; i < n - 1; ++i)
+            for (int k = 0; k <= NS; ++k) { seg[(size_t)i * (NS + 1) + k] = i; t[(size_t)i * (NS + 1) + k] = p(k); }
+        bs.pts = evaluate(bs.ctrl_pts, seg, t, ctx);
+        bs.positions.assign(n - 1, p);
         return bs;
     }
 
@@ -531,6 +734,7 @@ public:
         arclength_data ad;
         const int S = n_segments(), nsub = (int)std::lround(1.0f / precision);
         if (S == 0) return ad;
+        SC_ASSERT(degree() == 3, "arclength tables are built for cubic segments");
         std::vector<float> c(8 * (size_t)S), cum((size_t)S * (nsub + 1)), len(S);
         for (int i = 0; i < S; ++i)
             for (int k = 0; k < 4; ++k) { c[8 * i + 2 * k] = ctrl_pts[i][k].x(); c[8 * i + 2 * k + 1] = ctrl_pts[i][k].y(); }
@@ -569,9 +773,9 @@ public:
         for (int i = 0; i < n; ++i) profile_pos(i) = pp[i];
         bezier_spline re;
         re.ctrl_pts = ctrl_pts;
-        re.pts.resize(n);
+        re.pts = points_matrix::Zero(n, 2);
         std::vector<int> cnt(S, 0);
-        for (int i = 0; i < n; ++i) { re.pts[i] = Vector2f(out_pts[2 * i], out_pts[2 * i + 1]); ++cnt[sg[i]]; }
+        for (int i = 0; i < n; ++i) { re.pts(i, 0) = out_pts[2 * i]; re.pts(i, 1) = out_pts[2 * i + 1]; ++cnt[sg[i]]; }
         re.positions.clear();
         for (int s = 0, o = 0; s < S; ++s) {
             VectorXf v = VectorXf::Zero(cnt[s]);
@@ -582,29 +786,39 @@ public:
         return re;
     }
 
-    // signed curvature at every sample of `positions` (same as :1017-1039: hodograph and its hodograph)
+    // first derivative as a spline of its own: control points degree * (P[j+1] - P[j]) per segment, sampled at the same
+    // positions (:1041-1053)
+    bezier_spline hodograph(gpu_context& ctx = default_context()) const {
+        bezier_spline h;
+        const int S = n_segments(), deg = degree();
+        SC_ASSERT(deg >= 2, "the hodograph of a line has no control polygon");
+        std::vector<int32_t> seg;
+        std::vector<float> t;
+        for (int i = 0; i < S; ++i) {
+            std::vector<Vector2f> dc(deg);
+            for (int j = 0; j < deg; ++j) dc[j] = (ctrl_pts[i][j + 1] - ctrl_pts[i][j]) * (float)deg;
+            h.ctrl_pts.push_back(std::move(dc));
+            if (i < (int)positions.size())
+                for (size_t k = 0; k < (size_t)positions[i].rows(); ++k) { seg.push_back(i); t.push_back(positions[i](k)); }
+        }
+        h.positions = positions;
+        h.pts = evaluate(h.ctrl_pts, seg, t, ctx);
+        return h;
+    }
+
+    // signed curvature at every sample of `positions` (:1017-1039: hodograph and its hodograph)
     std::vector<float> curvature(gpu_context& ctx = default_context()) const {
-        const int S = n_segments();
-        std::vector<float> c(8 * (size_t)S), t;
-        std::vector<int32_t> sg;
-        for (int i = 0; i < S; ++i)
-            for (int k = 0; k < 4; ++k) { c[8 * i + 2 * k] = ctrl_pts[i][k].x(); c[8 * i + 2 * k + 1] = ctrl_pts[i][k].y(); }
-        for (int s = 0; s < (int)positions.size(); ++s)
-            for (size_t k = 0; k < (size_t)positions[s].rows(); ++k) { t.push_back(positions[s](k)); sg.push_back(s); }
-        const int M = (int)t.size();
-        std::vector<float> res(M);
-        if (M == 0) return res;
-        std::vector<float> d1(2 * (size_t)M), d2(2 * (size_t)M);
-        ctx.check(sc_bezier_eval_batch_host(ctx.get(), c.data(), S, sg.data(), t.data(), M, 1, d1.data()), "sc_bezier_eval_batch_host");
-        ctx.check(sc_bezier_eval_batch_host(ctx.get(), c.data(), S, sg.data(), t.data(), M, 2, d2.data()), "sc_bezier_eval_batch_host");
-        for (int i = 0; i < M; ++i) {
-            const float dx = d1[2 * i], dy = d1[2 * i + 1], ddx = d2[2 * i], ddy = d2[2 * i + 1];
+        const bezier_spline d = hodograph(ctx), dd = d.hodograph(ctx);
+        std::vector<float> res((size_t)d.n_pts());
+        for (size_t i = 0; i < res.size(); ++i) {
+            const float dx = d.pts(i, 0), dy = d.pts(i, 1), ddx = dd.pts(i, 0), ddy = dd.pts(i, 1);
             res[i] = (dx * ddy - dy * ddx) / std::pow(dx * dx + dy * dy, 1.5f);
         }
         return res;
     }
 
-    inline std::vector<float> angular_velocity(const velocity_profile& vel_prof) const;   // :1055-1067
+    inline std::vector<float> angular_velocity(const velocity_profile& vel_prof) const;    // :1055-1067
+    inline std::vector<float> angular_velocity2(const velocity_profile& vel_prof) const;   // :1069-1094 (no stdout prints)
 };
 
 // ---- velocity profile (sea_current.hpp:379-386, 1172-1265) ------------------------------------------
@@ -624,9 +838,19 @@ inline std::vector<float> bezier_spline::angular_velocity(const velocity_profile
     for (size_t i = 0; i < w.size(); ++i) w[i] = vel_prof.vel[0](i) * curv[i];
     return w;
 }
+// heading change of the tangent between consecutive samples over their time difference; zero at both ends
+inline std::vector<float> bezier_spline::angular_velocity2(const velocity_profile& vel_prof) const {
+    const bezier_spline d = hodograph();
+    const size_t n = (size_t)d.n_pts();
+    SC_ASSERT(n == (size_t)vel_prof.vel[0].size(), "hodograph and velocity vectors must be the same size");
+    std::vector<float> rads(n), res(n, 0.0f);
+    for (size_t i = 0; i < n; ++i) rads[i] = std::atan2(d.pts(i, 1), d.pts(i, 0));
+    for (size_t i = 1; i + 1 < n; ++i) res[i] = (rads[i + 1] - rads[i]) / (float)(vel_prof.time(i + 1) - vel_prof.time(i));
+    return res;
+}
 
 // limits as a function of the GRIDPOINT value s in [0,1] (the reference names the argument "time", :1175, :1185)
-using vel_lim_func = std::function<std::tuple<toppra_compat::Vector, toppra_compat::Vector>(value_type time)>;
+using vel_lim_func = std::function<std::tuple<toppra_compat::Vector, toppra_compat::Vector>(value_type time)>;   // = toppra::Vector
 
 constexpr int SC_TOPPRA_GRID = 100;  // toppra's default number of grid intervals (confirmed by examples/output.json)
 
@@ -744,12 +968,12 @@ inline std::string serialize_path_to_json(const bezier_spline& spline, const vel
     (void)arclens;
     std::string out = "[";
     char buf[512];
-    const size_t n = spline.pts.size();
+    const size_t n = (size_t)spline.pts.rows();
     for (size_t i = 0; i < n; ++i) {
         std::snprintf(buf, sizeof(buf),
                       "%s{\"acceleration\":%.9g,\"angularVelocity\":%.9g,\"holonomicAngularVelocity\":0.0,\"holonomicRotation\":0.0,"
                       "\"pose\":{\"translation\":{\"x\":%.9g,\"y\":%.9g}},\"time\":%.9g,\"velocity\":%.9g}",
-                      i ? "," : "", (double)vel_prof.acc[0](i), (double)ang_vel[i], (double)spline.pts[i].x(), (double)spline.pts[i].y(),
+                      i ? "," : "", (double)vel_prof.acc[0](i), (double)ang_vel[i], (double)spline.pts(i, 0), (double)spline.pts(i, 1),
                       (double)(float)vel_prof.time(i), (double)vel_prof.vel[0](i));
         out += buf;
     }

@@ -108,6 +108,7 @@ int main(int argc, char** argv) {
         planning_space free_space(br2);
         bezier_spline pad = bezier_spline::from_path({Vector2f(0, 0), Vector2f(10, 0), Vector2f(10, 10)}, free_space);
         CHECK(pad.n_segments() == 2 && pad.degree() == 3);
+        CHECK(pad.n_pts() == 2 * 10001 && pad.pts(0, 0) == 0.0f && std::fabs(pad.pts(20001, 1) - 10.0f) < 1e-6f);   // every leg sampled at 1e-4 (:679)
         CHECK(std::fabs(pad.ctrl_pts[0][1].x() - 5.0f) < 1e-5f && std::fabs(pad.ctrl_pts[1][2].y() - 5.0f) < 1e-5f);
         const arclength_data ad = pad.arclength();
         CHECK(std::fabs(ad.arclength - 21.38861656f) < 2e-5f);                 // output.json: arclength.arclength
@@ -141,8 +142,8 @@ int main(int argc, char** argv) {
         CHECK(re.n_pts() == (int)prof2.pos[0].rows() && re.n_pts() == 4328);
         CHECK(prof2.pos[0](0) == 0.0f && prof2.pos[0](4327) == ad.arclength);   // the nudge pins the ends (:903-904)
         float xmax = -1e9f, ymin = 1e9f;
-        for (const auto& p : re.pts) { xmax = std::max(xmax, p.x()); ymin = std::min(ymin, p.y()); }
-        CHECK(std::fabs(re.pts[0].x() - 0.00401974f) < 2e-5f && std::fabs(re.pts[4327].x() - 9.999999f) < 2e-5f && std::fabs(re.pts[4327].y() - 9.9983425f) < 2e-5f);   // output.json: pos_x/pos_y ends (the fit misses t = 0 by 2.7e-4)
+        for (int i = 0; i < re.n_pts(); ++i) { xmax = std::max(xmax, re.pts(i, 0)); ymin = std::min(ymin, re.pts(i, 1)); }
+        CHECK(std::fabs(re.pts(0, 0) - 0.00401974f) < 2e-5f && std::fabs(re.pts(4327, 0) - 9.999999f) < 2e-5f && std::fabs(re.pts(4327, 1) - 9.9983425f) < 2e-5f);   // output.json: pos_x/pos_y ends (the fit misses t = 0 by 2.7e-4)
         CHECK(std::fabs(xmax - 11.571348f) < 5e-5f && std::fabs(ymin + 1.5713487f) < 5e-5f);   // output.json: pos_x max, pos_y min
         const std::vector<float> w = re.angular_velocity(prof2);
         float wmax = 0;

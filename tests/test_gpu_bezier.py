@@ -154,3 +154,36 @@ def test_resample_batch_matches_oracle(ctx, oracle):
             assert np.abs(got["pts"][sl] - ref["pts"]).max() < 1e-5, b
             k = np.abs(ref["curvature"]) < 1e3                   # cusps of random splines: compare where curvature is sane
             assert np.allclose(got["curvature"][sl][k], ref["curvature"][k], rtol=2e-4, atol=1e-5), b
+
+
+def test_general_degree_curve_and_free_chebfit(ctx, oracle):
+    """sc_bezier_curve_batch (any degree) and sc_chebfit_batch / sc_chebeval_batch (the free functions of the header,
+    sea_current.hpp:700-763, 1109-1170) against the oracle; a fit with tens of thousands of rows as in examples/test.cpp:168."""
+    import torch
+    rng = np.random.default_rng(9)
+    for deg in (1, 2, 3, 6, 15):
+        ctrl = rng.uniform(-4, 4, (5, deg + 1, 2)).astype(np.float32)
+        seg = rng.integers(0, 5, 300).astype(np.int32)
+        t = rng.uniform(0, 1, 300).astype(np.float32)
+        got = ctx.bezier_curve(torch.from_numpy(ctrl).cuda(), torch.from_numpy(seg).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        want = oracle.bezier_curve(ctrl, seg, t.astype(np.float64))
+        assert np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+    # three problems of very different sizes in one batch
+    sizes = [7, 300, 20002]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = np.concatenate([np.sort(rng.uniform(-1, 5, n)) for n in sizes]).astype(np.float32)
+    y = (np.cos(1.3 * x) + 0.05 * x ** 3).astype(np.float32)
+    for degree in (3, 10):
+        coef, xr = ctx.chebfit(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(off).cuda(), degree)
+        yh = ctx.chebeval(torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda(), coef, xr).cpu().numpy()
+        coef, xr = coef.cpu().numpy(), xr.cpu().numpy()
+        for b, n in enumerate(sizes):
+            sl = slice(off[b], off[b + 1])
+            c_ref, xmin, xmax = oracle.chebfit(x[sl], y[sl], degree)
+            assert xr[b, 0] == np.float32(xmin) and xr[b, 1] == np.float32(xmax)
+            y_ref = oracle.chebeval(x[sl], c_ref, xmin, xmax)
+            # coefficients of an ill-conditioned small problem (7 rows, 10 columns would be rank deficient: skipped) move; values do not
+            if n > degree:
+                assert np.abs(yh[sl] - y_ref).max() < 5e-5 * max(1.0, np.abs(y_ref).max()), (degree, n)
+                if n >= 300:
+                    assert np.abs(coef[b] - c_ref).max() < 1e-4 * max(1.0, np.abs(c_ref).max())

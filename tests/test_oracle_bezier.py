@@ -103,3 +103,39 @@ def test_resample_nudge_and_split(oracle):
     s_of = np.array([lens[:g].sum() + np.interp(t, tk, cum[g]) for g, t in zip(r["seg"], r["t"])])
     want = np.concatenate([ref[:1], ref]).astype(np.float64)[np.arange(n) - r["seg"] + 1]   # output o of segment i is sample o - i
     assert np.abs(s_of - want).max() < 0.02 * AL
+
+
+def test_chebfit_is_the_least_squares_solution(oracle):
+    """The free chebfit (sea_current.hpp:1109-1138): `degree` Chebyshev columns of the abscissa normalised by its own
+    range; the restatement's Householder solution equals numpy's least-squares solution of the same system."""
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(-2, 7, 500)).astype(np.float32)
+    y = (np.sin(x) + 0.1 * x * x).astype(np.float32)
+    for degree in (1, 2, 5, 10):
+        coef, xmin, xmax = oracle.chebfit(x, y, degree)
+        assert xmin == x.min() and xmax == x.max()
+        xn = (2 * x.astype(np.float64) - (xmax + xmin)) / (xmax - xmin)
+        T = np.polynomial.chebyshev.chebvander(xn, degree - 1)
+        ref = np.linalg.lstsq(T, y.astype(np.float64), rcond=None)[0]
+        assert np.allclose(coef, ref, rtol=1e-9, atol=1e-9)
+        assert np.allclose(oracle.chebeval(x, coef, xmin, xmax), T @ ref, rtol=1e-9, atol=1e-9)
+
+
+def test_general_degree_curve_matches_bernstein_sum(oracle):
+    """bezier_curve for any control polygon (:700-763): de Casteljau equals the Bernstein sum; degree 3 equals the cubic
+    evaluation that is pinned to the recording; the hodograph's control points give the derivative."""
+    from math import comb
+    rng = np.random.default_rng(6)
+    t = np.linspace(0, 1, 41)
+    for deg in (1, 2, 3, 7):
+        ctrl = rng.uniform(-3, 3, (2, deg + 1, 2)).astype(np.float32)
+        seg = (np.arange(41) % 2).astype(np.int32)
+        got = oracle.bezier_curve(ctrl, seg, t)
+        B = np.stack([comb(deg, k) * t**k * (1 - t) ** (deg - k) for k in range(deg + 1)], 1)
+        want = np.einsum("mk,mkc->mc", B, ctrl[seg].astype(np.float64))
+        assert np.allclose(got, want, atol=1e-12)
+    ctrl = rng.uniform(-3, 3, (3, 4, 2)).astype(np.float32)
+    seg = (np.arange(41) % 3).astype(np.int32)
+    assert np.allclose(oracle.bezier_curve(ctrl, seg, t), oracle.bezier_eval(ctrl, seg, t, 0), atol=1e-12)
+    hod = (3 * (ctrl[:, 1:] - ctrl[:, :-1])).astype(np.float32)          # degree * (P[j+1] - P[j]), :1046
+    assert np.allclose(oracle.bezier_curve(hod, seg, t), oracle.bezier_eval(ctrl, seg, t, 1), atol=1e-5)
