@@ -66,7 +66,8 @@ typedef enum {
     SC_K_OCC = 9,         /* occupancy grid from a rectangle list (dynamic-obstacle frames) */
     SC_K_NEAREST = 10,    /* nearest obstacle cell from d2 */
     SC_K_FMT = 11,        /* FMT* over Halton samples (the reference's own planner), one wavefront per query */
-    SC_K_COUNT = 12
+    SC_K_GATHER = 12,     /* gather of result paths: pack, ncclAllGather, unpack */
+    SC_K_COUNT = 13
 } sc_kernel_id;
 
 #define SC_EDT_INF INT32_MAX /* d2 of every cell of a grid without obstacles */
@@ -259,6 +260,36 @@ int sc_fmt_star_batch(sc_ctx* ctx, const float* samples, int n, const float* sta
                       const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status);
 int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, const float* starts, const float* goals, int Q, float rn,
                            const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status);
+
+/* ---- multi-GPU: query sharding and the gather of result paths --------------------------------
+ * One process (context) per GPU.  Queries shard in contiguous blocks: rank r of `world` owns [q0, q1) as sc_rank_range
+ * says, plans them with sc_astar_batch on its own replica of the grid (every rank recomputes the EDT: cheaper than
+ * moving 4 B/cell), and sc_allgather_paths leaves EVERY rank with every query's result, in query order.  The reference
+ * has no collective of any kind (its only transport is the ZMQ REP loop, examples/zmq_test.cpp:18-22); this is the
+ * exchange BASELINE.json names ("RCCL all-gather of result paths over xGMI").
+ *
+ * Communicator: sc_comm_unique_id on one rank, the 128 bytes handed to all ranks by whatever launched them, then
+ * sc_comm_init on each (ncclCommInitRank); or sc_comm_adopt of an ncclComm_t the caller already has.  RCCL is loaded
+ * at run time (dlopen), so single-GPU users need no librccl.
+ *
+ * sc_allgather_paths (device pointers, enqueued on the context's stream, no host synchronisation):
+ *   in   path [Q_local][Lmax], len / cost / status [Q_local]   this rank's sc_astar_batch results
+ *   out  len_all / cost_all / status_all [Q_total], offsets_all int64 [Q_total + 1] (cells in front of each query;
+ *        only paths with status SC_Q_OK count), cells_all [cells_capacity] the paths back to back (may be NULL),
+ *        path_all [Q_total][Lmax] the fixed-stride parity layout (may be NULL), *truncated != 0 if some rank's paths
+ *        exceeded cap_cells (cells beyond it read -1; gather again with a larger cap_cells).
+ *   cap_cells: cells a rank's message can carry (the same on all ranks).  One ncclAllGather of
+ *        (2 + 3 ceil(Q_total / world) + cap_cells) int32 per rank. */
+void sc_rank_range(int Q, int world, int rank, int* q0, int* q1);
+int sc_comm_unique_id(void* id128);
+int sc_comm_init(sc_ctx* ctx, const void* id128, int nranks, int rank);
+int sc_comm_adopt(sc_ctx* ctx, void* nccl_comm, int nranks, int rank);
+int sc_comm_destroy(sc_ctx* ctx);
+int sc_allgather_paths(sc_ctx* ctx, const int32_t* path, const int32_t* len, const int32_t* cost, const int32_t* status,
+                       int Q_local, int Q_total, int Lmax, int cap_cells, int32_t* len_all, int32_t* cost_all, int32_t* status_all,
+                       int64_t* offsets_all, int32_t* cells_all, int64_t cells_capacity, int32_t* path_all, int32_t* truncated);
+/* bytes every rank received in the last sc_allgather_paths on this context */
+int sc_allgather_last_bytes(sc_ctx* ctx, int64_t* bytes);
 
 #ifdef __cplusplus
 }

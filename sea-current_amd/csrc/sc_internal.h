@@ -40,11 +40,16 @@ struct sc_ctx {
     sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
     sc_scratch bez_seginfo; // resample: int4 [S] (first sample, last sample, spline, segment in spline)
     sc_scratch cheb_a;      // chebfit: double [rows][degree + 1], the [T | y] matrices of a batch
+    sc_scratch gather_msg;  // gather: this rank's message, every rank's messages, local offsets
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 16;          // ring entries per bucket (power of two)
     size_t astar_slot_budget = (size_t)48 << 30;  // bytes of g + bucket scratch allowed
     int last_Q = 0;
     int edt_chain_token = -1;       // timing: colbits' end event doubles as band's start event
+    void* comm = nullptr;           // ncclComm_t of sc_allgather_paths
+    bool comm_owned = false;
+    int comm_ranks = 0, comm_rank = 0;
+    int64_t gather_bytes = 0;       // bytes every rank received in the last gather
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
 };
 

@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
 Q_OK, Q_NO_PATH, Q_BAD_ENDPOINT, Q_TRUNCATED, Q_RING_OVERFLOW = 0, 1, 2, 3, 4
-K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST, K_FMT = range(12)
+K_EDT_COLBITS, K_EDT_BAND, K_MOVES, K_ASTAR, K_TOPPRA, K_TOPPRA_SAMPLE, K_BEZIER, K_ARCLENGTH, K_RESAMPLE, K_OCC, K_NEAREST, K_FMT, K_GATHER = range(13)
 
 _lib = None
 
@@ -81,6 +81,13 @@ _SIGNATURES = {
     "sc_bezier_arclength_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "sc_bezier_resample_batch": (_i, [_vp] * 5 + [_i, _i, _i, _vp, _vp, _i] + [_vp] * 5),
     "sc_bezier_resample_batch_host": (_i, [_vp] * 5 + [_i, _i, _i, _vp, _vp, _i] + [_vp] * 5),
+    "sc_rank_range": (None, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "sc_comm_unique_id": (_i, [_vp]),
+    "sc_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "sc_comm_adopt": (_i, [_vp, _vp, _i, _i]),
+    "sc_comm_destroy": (_i, [_vp]),
+    "sc_allgather_paths": (_i, [_vp] * 5 + [_i, _i, _i, _i] + [_vp] * 5 + [C.c_int64, _vp, _vp]),
+    "sc_allgather_last_bytes": (_i, [_vp, _i64p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -202,6 +209,46 @@ class Context:
                                         _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]), _ptr(out["status"])),
                  "sc_astar_batch")
         return out
+
+    # ---- multi-GPU gather (RCCL through the C ABI) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes of an ncclUniqueId (call on one rank, hand to all)."""
+        buf = C.create_string_buffer(128)
+        st = lib().sc_comm_unique_id(buf)
+        if st != 0:
+            raise SeaCurrentError(f"sc_comm_unique_id: {lib().sc_status_string(st).decode()}")
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        self._ck(self._l.sc_comm_init(self._h, C.c_char_p(unique_id), world, rank), "sc_comm_init")
+        self.world, self.rank = world, rank
+
+    def allgather_paths(self, out, Q_total, cap_cells, want_path=False, bufs=None):
+        """Every rank's astar_batch results on every rank, in query order (sc_allgather_paths).  `out` = this rank's dict;
+        returns dict(len, cost, status [Q_total], offsets int64 [Q_total+1], cells [world*cap_cells], truncated [1], path?)."""
+        import torch
+        dev = out["len"].device
+        Ql, Lmax = out["path"].shape
+        world = getattr(self, "world", 1)
+        if bufs is None:
+            bufs = dict(len=torch.empty(Q_total, dtype=torch.int32, device=dev), cost=torch.empty(Q_total, dtype=torch.int32, device=dev),
+                        status=torch.empty(Q_total, dtype=torch.int32, device=dev),
+                        offsets=torch.empty(Q_total + 1, dtype=torch.int64, device=dev),
+                        cells=torch.empty(world * cap_cells, dtype=torch.int32, device=dev),
+                        truncated=torch.zeros(1, dtype=torch.int32, device=dev))
+            if want_path:
+                bufs["path"] = torch.empty((Q_total, Lmax), dtype=torch.int32, device=dev)
+        self._ck(self._l.sc_allgather_paths(self._h, _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]), _ptr(out["status"]), Ql, Q_total, Lmax,
+                                            cap_cells, _ptr(bufs["len"]), _ptr(bufs["cost"]), _ptr(bufs["status"]), _ptr(bufs["offsets"]),
+                                            _ptr(bufs["cells"]), bufs["cells"].numel(), _ptr(bufs.get("path")), _ptr(bufs["truncated"])),
+                 "sc_allgather_paths")
+        return bufs
+
+    def allgather_last_bytes(self):
+        n = C.c_int64()
+        self._ck(self._l.sc_allgather_last_bytes(self._h, C.byref(n)), "sc_allgather_last_bytes")
+        return n.value
 
     def astar_last_expansions(self):
         n = C.c_int64(0)
