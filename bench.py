@@ -3,18 +3,25 @@
 
 A "step" is one pass of the hot path over one batch: EDT of the 1024x1024 occupancy grid (recomputed
 every step: the grid is an input) + batched A* over this rank's start-goal queries [+ all-gather of
-the result paths when N > 1].  Inputs (grid, queries) are resident in HBM before the timed region.
+the result paths over RCCL when N > 1].  Inputs (grid, queries) are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Weak scaling: every rank plans `--queries` (default 1024) queries;
-value = (N * queries) / max-over-ranks step time.  Query i is the same on any rank count.
+value = (N * queries * K) / max-over-ranks time of the K steps.  Query i is the same on any rank count.
+
+Consecutive steps are independent batches.  No entry point of the library blocks the host any more, so the K steps
+are simply enqueued, round-robin, on `--depth` contexts (a context = one HIP stream + its scratch); a stream runs its
+steps in order, so a slot's buffers are never written by two steps at once.  One host thread, one synchronisation at
+the end.  `--depth 1` = strictly sequential steps on one stream (also reported in the default run as `value_depth1`).
 
 Also measured (outside the timed steps, reported in the same line):
   roofline     -- the EDT kernels on a batch of 64 grids (one 1024^2 grid is 5.2 MB: launch-bound
-                  and cache-resident), timed with HIP events inside the library on the
-                  stream the kernels run on; achieved = 5 B/cell * cells / (colbits + band time).
+                  and cache-resident, SURVEY.md 8d), timed with HIP events on the stream the kernels run on;
+                  achieved = 5 B/cell * cells / (colbits + band time).  Other map families and 4096^2 beside it.
+  configs2     -- BASELINE configs[2]: the same step plus TOPP-RA (6 joints, 200 stages) of 1024 plans.
+  replan_stream-- BASELINE configs[4] on one GPU.
   cpu_baseline -- the CPU oracle (our C restatement; the reference has no grid path and cannot be
                   built here) on a bounded sample of the same queries, all host cores.
 """
@@ -29,31 +36,24 @@ for _p in (ROOT, os.path.join(ROOT, "sea-current_amd", "python")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-# Independent steps are pipelined on separate HIP streams (--depth).  The HIP runtime multiplexes a process's streams
-# onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels that share a queue run one after the other; an A*
-# batch ends with its slowest query, so 4 concurrent batches leave most SIMDs idle.  Must be set before HIP starts.
-# 32 rather than 16: the 16 step streams must not share a queue with the stream RCCL's gather kernels run on (a gather
-# queued behind a 40 ms A* launch stalls the pipeline: measured -30 % with 16 queues, nothing with 24 or 32).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-
 import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 EDT_BYTES_PER_CELL = 5  # read occ 1 B + write d2 4 B
 
-
 FAMILIES = ("salt05", "salt20", "blocks")
 
 
-def make_grid(name, W, H):
+def make_grid(name, W, H, seed=None):
     from sea_current_amd import synth
+    kw = {} if seed is None else {"seed": seed}
     if name == "salt05":
-        return synth.salt_grid(W, H, 0.05)
+        return synth.salt_grid(W, H, 0.05, **kw)
     if name == "salt20":
-        return synth.salt_grid(W, H, 0.20)
+        return synth.salt_grid(W, H, 0.20, **kw)
     if name == "blocks":
-        return synth.block_grid(W, H, 0.20)
+        return synth.block_grid(W, H, 0.20, **kw)
     raise ValueError(name)
 
 
@@ -67,14 +67,15 @@ def main():
     ap.add_argument("--map", default="salt20", choices=list(FAMILIES),
                     help="obstacle family of the headline numbers (the other two are reported under other_maps)")
     ap.add_argument("--only-main-map", action="store_true")
-    ap.add_argument("--depth", type=int, default=16,
-                    help="independent steps in flight (own context/stream each); 1 = strictly sequential steps")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="contexts (streams) the steps are enqueued on round-robin; 1 = strictly sequential steps")
+    ap.add_argument("--group", type=int, default=0,
+                    help="consecutive steps handed to the library as ONE call (EDT with batch = group, sc_astar_batch_multi over "
+                         "group x queries): the launch then has one tail for `group` steps; 1 = one call per step; "
+                         "0 = min(16, steps / depth), so that every context gets the same number of calls whatever --steps is")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the "
-                         "multi-rank control flow with several ranks on one GPU: results are gathered through host copies)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--replan-frames", type=int, default=20,
                     help="frames of the dynamic-obstacle replan stream (BASELINE configs[4]) timed at N=1; 0 = skip")
@@ -83,24 +84,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
-    dist = None
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("launch with torch.distributed.run for --gpus > 1")
     ngpu = torch.cuda.device_count()
-    if args.backend == "gloo":
-        local_rank = local_rank % max(ngpu, 1)     # rehearsal: ranks may share a GPU
+    local_rank = local_rank % max(ngpu, 1)            # rehearsals with several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # SC_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank) drives the collective path with a world of one:
-    # the only way to run the RCCL gather of the timed loop on a one-GPU box
-    use_dist = world > 1 or bool(os.environ.get("SC_BENCH_FORCE_DIST"))
-    if use_dist:
+    # The data path's only collective is the library's own (sc_allgather_paths, RCCL through the C ABI); the process
+    # group is control plane only (barriers, the max over ranks of the step time, handing out the RCCL unique ids), on
+    # gloo.  SC_BENCH_FORCE_DIST=1 drives the gather with a world of one (the only way to run it on a one-GPU box).
+    dist = None
+    if world > 1:
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo")
+    use_gather = world > 1 or bool(os.environ.get("SC_BENCH_FORCE_DIST"))
 
     import sea_current_amd as sc
     from sea_current_amd import synth, shard
@@ -108,154 +105,198 @@ def main():
     W = H = args.size
     Qloc = args.queries
     Qtot = Qloc * world
-    ctx = sc.Context(local_rank)
     q0, q1 = shard.rank_range(Qtot, world, rank)
+    depth_max = max(1, args.depth)
+    ctxs = [sc.Context(local_rank, use_torch_stream=False) for _ in range(depth_max)]
+    ctx = ctxs[0]
+    if use_gather:
+        for c in ctxs:   # one communicator per context, created in the same order on every rank
+            if world > 1:
+                box = [sc.Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            else:
+                uid = sc.Context.comm_unique_id()
+            c.comm_init(uid, world, rank)
 
     def fence():
-        for c in slot_ctx:
+        for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
-        if use_dist:
+        if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
 
-    import threading
-    depth_max = max(1, args.depth)
-    slot_ctx = [ctx] + [sc.Context(local_rank, use_torch_stream=False) for _ in range(depth_max - 1)]
-    if depth_max > 1:
-        ctx.use_own_stream()
+    def alloc_out(G=1):
+        return dict(path=torch.empty((G * Qloc, args.lmax), dtype=torch.int32, device=dev),
+                    len=torch.empty(G * Qloc, dtype=torch.int32, device=dev),
+                    cost=torch.empty(G * Qloc, dtype=torch.int32, device=dev),
+                    status=torch.empty(G * Qloc, dtype=torch.int32, device=dev))
 
-    def run_map(family, steps, warmup, depth):
-        """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ all-gather]).
+    # a rank's message carries at most this many path cells: 1/4 of the fixed-stride volume (mean path 519 of 4096 cells
+    # on the headline map); a rank whose paths do not fit is flagged in `gather.truncated`
+    cap_cells = Qloc * args.lmax // 4
 
-        depth == 1: strictly sequential steps.  depth > 1: consecutive steps are independent batches, so
-        they are executed by `depth` slots (own sc_ctx + HIP stream + output buffers + host thread) and
-        overlap on the GPU -- an A* batch ends with its slowest query, which leaves most CUs idle for
-        most of a step.  Every step still runs its own EDT and A* over all its queries; the gather of
-        step i is issued by the main thread, in step order, once slot i % depth has finished it."""
+    def run_map(family, steps, warmup, depth, with_toppra=False, group=1):
+        """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ gather] [+ TOPP-RA]) on `depth` contexts,
+        `group` consecutive steps per library call (every step still has its own grid buffer, distance map and results)."""
+        G = max(1, min(group, steps))
         occ_h = make_grid(family, W, H)
-        occ = torch.from_numpy(occ_h).to(dev)
-        d2s = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(depth)]
-        ctx.edt(occ, out=d2s[0].view(1, H, W))
+        occ = torch.from_numpy(np.stack([occ_h] * G)).to(dev)          # the grids of G steps (inputs; same content)
+        d2s = [torch.empty((G, H, W), dtype=torch.int32, device=dev) for _ in range(depth)]
+        ctx.edt(occ, out=d2s[0])
         ctx.synchronize()
-        torch.cuda.synchronize()
         # queries are drawn from the largest free component (needs the traversable mask once, on the host)
-        s_h, g_h = synth.queries(d2s[0].cpu().numpy() >= 1, q1 - q0, first=q0)
-        start = torch.from_numpy(s_h).to(dev)
-        goal = torch.from_numpy(g_h).to(dev)
-        outs = [dict(path=torch.empty((Qloc, args.lmax), dtype=torch.int32, device=dev),
-                     len=torch.empty(Qloc, dtype=torch.int32, device=dev),
-                     cost=torch.empty(Qloc, dtype=torch.int32, device=dev),
-                     status=torch.empty(Qloc, dtype=torch.int32, device=dev)) for _ in range(depth)]
-        gathered = [shard.alloc_gather(outs[j], world) if use_dist else None for j in range(depth)]
+        s_h, g_h = synth.queries(d2s[0][0].cpu().numpy() >= 1, q1 - q0, first=q0)
+        start = torch.from_numpy(np.tile(s_h, G)).to(dev)
+        goal = torch.from_numpy(np.tile(g_h, G)).to(dev)
+        qgrid = torch.from_numpy(np.repeat(np.arange(G, dtype=np.int32), Qloc)).to(dev)
+        outs = [alloc_out(G) for _ in range(depth)]
+        gath = [[None] * G for _ in range(depth)]
+        tp_args = None
+        if with_toppra:
+            pl = synth.toppra_plans(Qloc, dof=6, first=q0)
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            tp_args = (tt(pl["p0"]), tt(pl["p1"]), tt(pl["v0"]), tt(pl["v1"]), tt(-pl["vlim"]), tt(pl["vlim"]), tt(-pl["alim"]), tt(pl["alim"]))
         torch.cuda.synchronize()
+        tp_last = [None]
+        keep = []   # TOPP-RA outputs stay alive until the streams are idle (they are allocated by torch, used on our streams)
+
+        def view(o, k):   # step k of a group's results
+            return {kk: vv[k * Qloc:(k + 1) * Qloc] for kk, vv in o.items()}
 
         def run_steps(nsteps):
-            done = [threading.Event() for _ in range(nsteps)]
-            released = [threading.Event() for _ in range(nsteps)]
-            errors = []
+            assert nsteps % G == 0
+            for i in range(nsteps // G):
+                j = i % depth
+                c = ctxs[j]
+                c.edt(occ, out=d2s[j])
+                if G == 1:
+                    c.astar_batch(d2s[j][0], start, goal, r2=0, Lmax=args.lmax, out=outs[j])
+                else:
+                    c.astar_batch_multi(d2s[j], qgrid, start, goal, r2=0, Lmax=args.lmax, out=outs[j])
+                for k in range(G):
+                    if use_gather:
+                        gath[j][k] = c.allgather_paths(view(outs[j], k), Qtot, cap_cells, bufs=gath[j][k])
+                    if with_toppra:
+                        tp = c.toppra(*tp_args, N=200)
+                        tp_last[0] = (tp, c.toppra_sample(tp_args[0], tp_args[1], tp_args[2], tp_args[3], tp["x"], tp["t"], 0.02, 512))
+                        keep.append(tp_last[0])
 
-            def worker(j):
-                try:
-                    for i in range(j, nsteps, depth):
-                        if i - depth >= 0:
-                            released[i - depth].wait()      # this slot's buffers have been gathered
-                        slot_ctx[j].edt(occ, out=d2s[j].view(1, H, W))
-                        slot_ctx[j].astar_batch(d2s[j], start, goal, r2=0, Lmax=args.lmax, out=outs[j])
-                        slot_ctx[j].synchronize()
-                        done[i].set()
-                except Exception as e:  # surface failures of worker threads
-                    errors.append(e)
-                    for ev in done:
-                        ev.set()
-
-            ths = [threading.Thread(target=worker, args=(j,)) for j in range(depth)]
-            for t in ths:
-                t.start()
-            for i in range(nsteps):
-                done[i].wait()
-                if use_dist and not errors:
-                    if args.backend == "nccl":
-                        shard.allgather_paths(outs[i % depth], gathered[i % depth], dist)
-                        torch.cuda.current_stream().synchronize()
-                    else:  # gloo rehearsal: gather through host memory
-                        host_out = {k: v.cpu() for k, v in outs[i % depth].items()}
-                        host_all = shard.allgather_paths(host_out, shard.alloc_gather(host_out, world), dist)
-                        for k in host_all:
-                            gathered[i % depth][k].copy_(host_all[k])
-                released[i].set()
-            for t in ths:
-                t.join()
-            if errors:
-                raise errors[0]
-
-        run_steps(max(warmup, depth))   # every slot allocates its scratch on its first step: keep that out of the timed region
+        steps = ((steps + G - 1) // G) * G              # whole groups: K is rounded up to a multiple of the group (reported)
+        run_steps(((max(warmup, depth * G) + G - 1) // G) * G)   # every context allocates its scratch on its first call: not timed
         fence()
+        keep.clear()
         ctx.set_timing(True)
         ctx.reset_timing()
         t0 = time.perf_counter()
         run_steps(steps)
+        t_enq = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-            # every rank must now hold every rank's results, in query order
-            gl = gathered[(steps - 1) % depth]["len"].cpu().numpy()
-            mine = outs[(steps - 1) % depth]["len"].cpu().numpy()
-            assert gl.shape[0] == Qtot and np.array_equal(gl[q0:q1], mine), "gather of result paths is inconsistent"
-        step_kernels = {}
-        nslot0 = max(1, len(range(0, steps, depth)))   # timing is collected on slot 0 only
-        for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR)):
+        if dist is not None:
+            tt_ = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            dt = float(tt_.item())
+        kern = {}
+        for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR),
+                          ("gather", sc.K_GATHER), ("toppra", sc.K_TOPPRA), ("toppra_sample", sc.K_TOPPRA_SAMPLE)):
             ms, n = ctx.get_timing(kid)
-            step_kernels[name] = {"ms_per_step": ms / nslot0, "launches": n}
+            if n:
+                kern[name] = {"ms_per_launch_on_context0": ms / n, "launches": n}
         ctx.set_timing(False)
-        expansions = ctx.astar_last_expansions()
-        out = outs[0]
+        expansions = ctx.astar_last_expansions() // G
+        out = view(outs[0], 0)
         st = out["status"].cpu().numpy()
         ln = out["len"].cpu().numpy()
-        astar_ms = step_kernels["astar"]["ms_per_step"]
-        return dict(value=Qtot * steps / dt, ms_per_step=1e3 * dt / steps, step_kernels=step_kernels,
-                    astar={"expansions_per_step_rank0": expansions,
-                           "expansions_per_s_rank0": expansions / (astar_ms * 1e-3) if astar_ms > 0 else None,
-                           "algorithmic_GBps_rank0": 104 * expansions / (astar_ms * 1e-3) / 1e9 if astar_ms > 0 else None,
-                           "found": int((st == 0).sum()), "no_path": int((st == 1).sum()),
-                           "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
-                    _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st))
+        astar_ms = kern["astar"]["ms_per_launch_on_context0"]
+        res = dict(value=Qtot * steps / dt, ms_per_step=1e3 * dt / steps, host_enqueue_ms_per_step=1e3 * t_enq / steps, kernels=kern,
+                   astar={"expansions_per_step_rank0": expansions,
+                          "launch_ms_on_context0": astar_ms,
+                          "expansions_per_s_whole_job": expansions * world * steps / dt,
+                          "algorithmic_GBps_whole_job": 104 * expansions * world * steps / dt / 1e9,
+                          "found": int((st == 0).sum()), "no_path": int((st == 1).sum()), "ring_overflow": int((st == 4).sum()),
+                          "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
+                   steps=steps, group=G,
+                   _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st, d2=d2s[0][0], gath=gath[0][0]))
+        if with_toppra:
+            res["toppra_ok"] = int((tp_last[0][0]["status"] == 0).sum())
+        return res
 
-    main_run = run_map(args.map, args.steps, args.warmup, depth_max)
-    seq_run = run_map(args.map, max(2, min(args.steps, 3)), 1, 1) if depth_max > 1 else main_run
-    others = {} if args.only_main_map else {f: run_map(f, max(depth_max, min(args.steps, 4)), 1, depth_max) for f in FAMILIES if f != args.map}
+    if args.group <= 0:
+        args.group = max(1, min(16, -(-args.steps // depth_max)))
+    main_run = run_map(args.map, args.steps, args.warmup, depth_max, group=args.group)
+    seq_run = run_map(args.map, max(2, min(args.steps, 4)), 1, 1)                     # one call per step, one stream
+    others = {} if args.only_main_map else {f: run_map(f, args.steps, 1, depth_max, group=args.group) for f in FAMILIES if f != args.map}
+    cfg2 = run_map(args.map, args.steps, 1, depth_max, with_toppra=True, group=args.group)
     occ_h, s_h, g_h, out, st = (main_run["_host"][k] for k in ("occ", "s", "g", "out", "st"))
+
+    # ---- the gather must have left every rank with every rank's paths, in query order ----
+    gather_info = None
+    if use_gather:
+        ga = main_run["_host"]["gath"]
+        off = ga["offsets"].cpu().numpy()
+        cells = ga["cells"].cpu().numpy()
+        mine_p = out["path"].cpu().numpy()
+        mine_l = out["len"].cpu().numpy()
+        ok = bool(np.array_equal(ga["len"].cpu().numpy()[q0:q1], mine_l) and np.array_equal(ga["status"].cpu().numpy()[q0:q1], st)
+                  and np.array_equal(ga["cost"].cpu().numpy()[q0:q1], out["cost"].cpu().numpy()))
+        for q in range(Qloc):
+            if st[q] == 0:
+                ok = ok and np.array_equal(cells[off[q0 + q]:off[q0 + q] + mine_l[q]], mine_p[q, :mine_l[q]])
+        # paths of ANOTHER rank's block: replan a sample of its queries here (query i is the same on any rank) and compare
+        checked_other = 0
+        if world > 1:
+            r2_ = (rank + 1) % world
+            o0, o1 = shard.rank_range(Qtot, world, r2_)
+            ns = min(64, o1 - o0)
+            so, go = synth.queries(main_run["_host"]["d2"].cpu().numpy() >= 1, ns, first=o0)
+            oo = ctx.astar_batch(main_run["_host"]["d2"], torch.from_numpy(so).to(dev), torch.from_numpy(go).to(dev), Lmax=args.lmax)
+            ctx.synchronize()
+            op, ol, ost = oo["path"].cpu().numpy(), oo["len"].cpu().numpy(), oo["status"].cpu().numpy()
+            gl, gs = ga["len"].cpu().numpy(), ga["status"].cpu().numpy()
+            for q in range(ns):
+                ok = ok and gs[o0 + q] == ost[q] and gl[o0 + q] == ol[q]
+                if ost[q] == 0:
+                    ok = ok and np.array_equal(cells[off[o0 + q]:off[o0 + q] + ol[q]], op[q, :ol[q]])
+            checked_other = ns
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist is not None:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        assert int(okt.item()) == 1, "gather of result paths is inconsistent"
+        gather_info = {"entry_point": "sc_allgather_paths (pack kernel -> one ncclAllGather over RCCL -> unpack kernel)",
+                       "bytes_received_per_rank_per_step": ctx.allgather_last_bytes(),
+                       "fixed_stride_bytes_per_rank_per_step": Qtot * (args.lmax + 3) * 4,
+                       "cells_per_rank_capacity": cap_cells, "truncated": int(ga["truncated"][0]),
+                       "paths_checked": "own block, cell for cell" + (f"; {checked_other} queries of rank {(rank + 1) % world}'s block replanned here and compared" if world > 1 else ""),
+                       "consistent_on_all_ranks": True}
 
     result = None
     if rank == 0:
         result = {
             "metric": "plans/sec (batched start-goal, 1024^2 grid)", "value": main_run["value"], "unit": "plans/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_run["ms_per_step"],
+            "n_gpus": world, "steps": main_run["steps"], "warmup": args.warmup, "ms_per_step": main_run["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} random-obstacle grid ({args.map}), EDT + A*, {Qloc} batched queries per GPU"
-                                   + (", RCCL all-gather of paths" if world > 1 else ""),
+                                   + (", RCCL all-gather of paths" if use_gather else ""),
                        "grid": [W, H], "map": args.map, "queries_per_gpu": Qloc, "queries_total": Qtot, "lmax": args.lmax,
-                       "parallelism": f"query-sharded x{world}", "pipeline_depth": depth_max,
-                                  "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
-            "latency_ms_per_step_sequential": seq_run["ms_per_step"], "value_sequential": seq_run["value"],
-            "step_kernels": main_run["step_kernels"], "astar": main_run["astar"],
-            "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"], "astar_ms_per_step": r["step_kernels"]["astar"]["ms_per_step"],
+                       "parallelism": f"query-sharded x{world}", "contexts_in_flight": depth_max, "steps_per_call": main_run["group"],
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default")},
+            "value_depth1": seq_run["value"], "ms_per_step_depth1": seq_run["ms_per_step"],
+            "host_enqueue_ms_per_step": main_run["host_enqueue_ms_per_step"],
+            "kernels": main_run["kernels"], "astar": main_run["astar"],
+            "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"],
                                "expansions_per_step_rank0": r["astar"]["expansions_per_step_rank0"]} for f, r in others.items()},
+            "configs2": {"workload": f"the same step + TOPP-RA (6 joints, 200 stages, sampled at 20 ms) of {Qloc} plans per GPU",
+                         "value": cfg2["value"], "ms_per_step": cfg2["ms_per_step"], "toppra_ok": cfg2.get("toppra_ok")},
         }
+        if gather_info:
+            result["gather"] = gather_info
 
     # ---- roofline leg: EDT on a batch of grids (rank 0 only, N = 1 semantics) ----
     if rank == 0:
-        B = args.edt_batch
-        d2b = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-
-        def edt_leg(family):
-            grids = torch.from_numpy(np.stack([
-                synth.salt_grid(W, H, 0.05, seed=synth.SEED_GRID + i) if family == "salt05" else
-                synth.salt_grid(W, H, 0.20, seed=synth.SEED_GRID + i) if family == "salt20" else
-                synth.block_grid(W, H, 0.20, seed=synth.SEED_GRID + i) for i in range(B)])).to(dev)
+        def edt_leg(family, Wl, Hl, B):
+            grids = torch.from_numpy(np.stack([make_grid(family, Wl, Hl, seed=synth.SEED_GRID + i) for i in range(B)])).to(dev)
+            d2b = torch.empty((B, Hl, Wl), dtype=torch.int32, device=dev)
             # HIP events on the stream the kernels are launched on: `iters` EDTs back to back inside ONE bracket, so the
             # few microseconds an event pair costs are not charged to every 70 us launch
             ts = torch.cuda.Stream(device=dev)
@@ -280,18 +321,20 @@ def main():
             ms_a, _ = ctx.get_timing(sc.K_EDT_COLBITS)
             ms_b, _ = ctx.get_timing(sc.K_EDT_BAND)
             ctx.set_timing(False)
-            ctx.use_own_stream() if depth_max > 1 else ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            alg_bytes = EDT_BYTES_PER_CELL * B * W * H
+            ctx.use_own_stream()
+            alg_bytes = EDT_BYTES_PER_CELL * B * Wl * Hl
             achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+            del grids, d2b
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": "edt_colbits_kernel + edt_band_kernel (one EDT = both launches)",
-                    "workload": f"EDT of {B} x {W}x{H} {family} grids per launch pair",
+                    "workload": f"EDT of {B} x {Wl}x{Hl} {family} grids per launch pair",
                     "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": per_launch_ms,
                     "timing": f"HIP events around {iters} back-to-back EDTs on the launch stream",
                     "ms_colbits_bracketed": ms_a / iters, "ms_band_bracketed": ms_b / iters}
 
-        legs = {fam: edt_leg(fam) for fam in ("salt05", "salt20", "blocks")}
+        B = args.edt_batch
+        legs = {fam: edt_leg(fam, W, H, B) for fam in FAMILIES}
         result["roofline"] = legs[args.map]
         # measured device-to-device copy bandwidth on this box (256 MiB read + 256 MiB written per copy), for scale
         src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
@@ -309,21 +352,28 @@ def main():
         result["roofline"]["measured_copy_GBps"] = copy_gbs
         result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / copy_gbs
         del src, dst
+        # HBM traffic of the same workload from the PMC counters: collected by rocprofv3 in separate passes (the counters
+        # cannot be read from inside this process), kept under profiles/ with the command that made them
         tpath = os.path.join(ROOT, "profiles", "edt_traffic.json")
         if os.path.exists(tpath) and (W, H, args.edt_batch) == (1024, 1024, 64):
             try:
-                result["roofline"]["traffic"] = json.load(open(tpath)).get(args.map, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                result["roofline"]["traffic"] = tj.get(args.map, {}).get("hbm_bytes_per_launch")
+                result["roofline"]["traffic_source"] = "profiles/edt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)"
             except Exception:
                 pass
-        result["roofline_other_maps"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "ms_per_launch", "ms_colbits_bracketed", "ms_band_bracketed")}
-                                         for k, v in legs.items() if k != args.map}
-        del d2b
+        keys = ("achieved", "frac", "ms_per_launch", "ms_colbits_bracketed", "ms_band_bracketed")
+        result["roofline_other_maps"] = {k: {kk: v[kk] for kk in keys} for k, v in legs.items() if k != args.map}
+        if (W, H) == (1024, 1024):   # BASELINE configs[3]'s grid: the same number of cells per launch pair
+            result["roofline_4096"] = {fam: {kk: v[kk] for kk in keys + ("workload",)}
+                                       for fam, v in ((f, edt_leg(f, 4096, 4096, max(1, B // 16))) for f in ("salt20", "blocks"))}
 
-        # ---- TOPP-RA leg (BASELINE configs[2]: 1k plans, 6-DOF, 200 waypoints): reported, not part of `value` ----
+        # ---- TOPP-RA leg (BASELINE configs[2]: 1k plans, 6-DOF, 200 waypoints): the kernels alone ----
         P, dof, N = 1024, 6, 200
         pl = synth.toppra_plans(P, dof=dof)
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         targs = (tt(pl["p0"]), tt(pl["p1"]), tt(pl["v0"]), tt(pl["v1"]), tt(-pl["vlim"]), tt(pl["vlim"]), tt(-pl["alim"]), tt(pl["alim"]))
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         for _ in range(2):
             tp = ctx.toppra(*targs, N=N)
         torch.cuda.synchronize()
@@ -416,9 +466,9 @@ def main():
                                   "gpu_matches_cpu_on_sample": ok}
     if rank == 0:
         print(json.dumps(result))
-    for c in slot_ctx:
+    for c in ctxs:
         c.close()
-    if use_dist:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

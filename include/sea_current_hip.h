@@ -141,6 +141,12 @@ int sc_astar_batch(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clea
 int sc_astar_batch_host(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
                         const int32_t* start, const int32_t* goal, int Q, int Lmax,
                         int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
+/* Several grids in one launch: d2 int32 [G][H][W] (e.g. from sc_edt_u8_i32 with batch = G), qgrid int32 [Q] the grid of
+ * every query.  Independent problems (several maps, several robots' local maps, consecutive frames) then share ONE
+ * launch and its single tail: the persistent wavefronts pull queries of all grids from one queue, longest first. */
+int sc_astar_batch_multi(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid, int W, int H, int32_t r2_clear,
+                         const int32_t* start, const int32_t* goal, int Q, int Lmax,
+                         int32_t* path, int32_t* len, int32_t* cost, int32_t* status);
 /* Node expansions of the last sc_astar_batch call on this context (synchronises). */
 int sc_astar_last_expansions(sc_ctx* ctx, int64_t* expansions);
 /* Debug: per-query expansions, popped queue entries, kilo-cycles and steps (int32 [4][Q]) of the last sc_astar_batch

@@ -61,6 +61,7 @@ struct astar_args {
     int32_t rmin;
     const int32_t* start;
     const int32_t* goal;
+    const int32_t* qgrid;    // optional: grid of every query (several grids in one launch); NULL = all on grid 0
     const int32_t* order;    // optional: query index of the i-th queue position
     const int32_t* nq_dev;   // optional: number of queue positions, read from the device (retry pass)
     int nq;                  // number of queue positions otherwise
@@ -230,7 +231,9 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     // single exit: the outcome is collected here and written once at the end (early returns inside the query loop
     // of the kernel gave the compiler an irreducible region to structurise)
     int out_st = SC_Q_OK, out_len = 0, out_cost = -1, nexp = 0, npop = 0, kcyc = 0, nstep = 0;
-    const bool bad = s < 0 || t < 0 || (size_t)s >= cells || (size_t)t >= cells || a.d2[s] < a.rmin || a.d2[t] < a.rmin;
+    const size_t grid_off = a.qgrid ? (size_t)a.qgrid[q] * cells : 0;   // this query's grid among the launch's
+    const uint8_t* const mvs = a.moves + grid_off;
+    const bool bad = s < 0 || t < 0 || (size_t)s >= cells || (size_t)t >= cells || a.d2[grid_off + s] < a.rmin || a.d2[grid_off + t] < a.rmin;
     if (bad) out_st = SC_Q_BAD_ENDPOINT;
     else if (s == t) {
         if (lane == 0) path[0] = s;
@@ -345,7 +348,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int adx = abs(gx - x), ady = abs(gy - y);
                 const int lgeom = d >= 4 ? min(adx, ady) : abs(adx - ady);
                 const int lmax = valid && df == 0 ? min(RUNK, lgeom) : 1;     // df == 0 implies lgeom >= 1
-                const uint8_t* const cell = a.moves + (y * W + x);             // invalid lanes read cell 0: harmless
+                const uint8_t* const cell = mvs + (y * W + x);             // invalid lanes read cell 0: harmless
                 const uint8_t* ra[RUNK - 1];
                 uint32_t rm[RUNK - 1];
 #pragma unroll
@@ -380,7 +383,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int x = e & 0x1FFF, y = e >> 19;
                 const uint32_t bit = 1u << (x & 31);
                 uint32_t old = 0, pmv;
-                pop_pair_issue(a.moves + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
+                pop_pair_issue(mvs + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
                 const uint32_t prune = entry_prune(e);
                 const int hc = octile(x, y, gx, gy);
                 pop_pair_wait_load(pmv, old);
@@ -462,7 +465,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int nx = cx - ddx[d], ny = cy - ddy[d];
                 if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
                     const int n = ny * W + nx;
-                    if ((a.moves[n] >> d) & 1) {
+                    if ((mvs[n] >> d) & 1) {
                         const uint32_t cw = g_load(&cl[cix(nx, ny, bw)]);
                         const uint32_t gn = g_load(&g[gix(nx, ny, tw)]);
                         ok = ((cw >> (nx & 31)) & 1u) && gn == gc - (d < 4 ? 10u : 14u);  // closed in this search and g[n] + w == g[c]
@@ -573,7 +576,7 @@ static int astar_resident_waves(sc_ctx* ctx) {
     return w;
 }
 
-static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, const int32_t* start,
+static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid, int W, int H, int32_t r2, const int32_t* start,
                      const int32_t* goal, int Q, int Lmax, int32_t* path, int32_t* len, int32_t* cost,
                      int32_t* status) {
     const size_t cells = (size_t)W * H;
@@ -581,9 +584,9 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
     const size_t gcells = (size_t)tw * ((H + 3) >> 2) * 16;   // g array: whole 4 x 4 tiles
     const size_t bwords = (size_t)bw * ((H + 15) >> 4) * 16;  // closed bitmap: whole 32 x 16 tiles
     const int32_t rmin = r2 > 1 ? r2 : 1;
-    int r = sc_scratch_reserve(ctx, &ctx->moves, cells);
+    int r = sc_scratch_reserve(ctx, &ctx->moves, cells * (size_t)G);
     if (r != SC_OK) return r;
-    r = sc_launch_moves(ctx, d2, W, H, r2, (uint8_t*)ctx->moves.p);
+    r = sc_launch_moves(ctx, d2, W, H * G, H, r2, (uint8_t*)ctx->moves.p);   // G grids stacked: one launch
     if (r != SC_OK) return r;
     // qstats: expanded[Q] | popped[Q] | kilo-cycles[Q] | steps[Q] | order[Q] | ovf_list[Q]
     r = sc_scratch_reserve(ctx, &ctx->qstats, (size_t)Q * 6 * sizeof(int32_t));
@@ -624,7 +627,7 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, c
     const bool sorted = (size_t)Q > slots;   // every query starts at once otherwise
     int tk = sc_time_begin(ctx, SC_K_ASTAR);
     hipLaunchKernelGGL(astar_prep_kernel, dim3(1), dim3(1024), 0, ctx->stream, start, goal, Q, W, H, sorted ? order : (int32_t*)nullptr, ctr);
-    astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, sorted ? order : nullptr, nullptr, Q, Lmax, path, len,
+    astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, qgrid, sorted ? order : nullptr, nullptr, Q, Lmax, path, len,
                  cost, status, (uint32_t*)ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
                  ovf_list, ctr + 1, ctr + 4, Q, tw, bw, gcells, bwords};
     hipLaunchKernelGGL(astar_kernel, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
@@ -650,7 +653,18 @@ extern "C" int sc_astar_batch(sc_ctx* ctx, const int32_t* d2, int W, int H, int3
         return SC_ERR_INVALID;
     if (Q == 0) return SC_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    return astar_run(ctx, d2, W, H, r2_clear, start, goal, Q, Lmax, path, len, cost, status);
+    return astar_run(ctx, d2, 1, nullptr, W, H, r2_clear, start, goal, Q, Lmax, path, len, cost, status);
+}
+
+extern "C" int sc_astar_batch_multi(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid, int W, int H, int32_t r2_clear,
+                                    const int32_t* start, const int32_t* goal, int Q, int Lmax,
+                                    int32_t* path, int32_t* len, int32_t* cost, int32_t* status) {
+    if (!ctx || !d2 || !qgrid || !start || !goal || !path || !len || !cost || !status || G <= 0 || W <= 0 || H <= 0 || Q < 0 ||
+        Lmax <= 0 || W > SC_MAX_DIM || H > SC_MAX_DIM || (long long)H * G > 0x7FFFFFFF / (W > 0 ? W : 1))
+        return SC_ERR_INVALID;
+    if (Q == 0) return SC_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    return astar_run(ctx, d2, G, qgrid, W, H, r2_clear, start, goal, Q, Lmax, path, len, cost, status);
 }
 
 extern "C" int sc_astar_last_expansions(sc_ctx* ctx, int64_t* expansions) {
@@ -680,7 +694,7 @@ extern "C" int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int
     SC_HIP(ctx, hipMemcpyAsync(sg, h, 8, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // Lmax = 1: the path is not wanted; a found path reports SC_Q_TRUNCATED
-    r = astar_run(ctx, d2, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status);
+    r = astar_run(ctx, d2, 1, nullptr, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status);
     if (r != SC_OK) return r;
     // one query: it ran in slot 0 of the main pass, or of the retry pass (same slot 0)
     hipLaunchKernelGGL(gfield_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -822,11 +822,13 @@ extern "C" int sc_edt_u8_i32(sc_ctx* ctx, const uint8_t* occ, int W, int H, int 
 
 // ---- legal-move mask --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-moves_kernel(const int32_t* __restrict__ d2, int W, int H, int32_t rmin, uint8_t* __restrict__ moves) {
+moves_kernel(const int32_t* __restrict__ d2, int W, int Hall, int H, int32_t rmin, uint8_t* __restrict__ moves) {
+    // Hall = G * H rows: G grids of H rows stacked; a cell's neighbours are looked up inside its own grid only
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    const int yall = blockIdx.y;
     if (x >= W) return;
-    const int32_t* r1 = d2 + (size_t)y * W;
+    const int y = yall % H;
+    const int32_t* r1 = d2 + (size_t)yall * W;
     bool t[3][3];
 #pragma unroll
     for (int j = -1; j <= 1; ++j)
@@ -847,13 +849,13 @@ moves_kernel(const int32_t* __restrict__ d2, int W, int H, int32_t rmin, uint8_t
         m |= (uint32_t)(t[0][2] && t[1][2] && t[0][1]) << 6;
         m |= (uint32_t)(t[0][0] && t[1][0] && t[0][1]) << 7;
     }
-    moves[(size_t)y * W + x] = (uint8_t)m;
+    moves[(size_t)yall * W + x] = (uint8_t)m;
 }
 
-int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, uint8_t* moves) {
+int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int Hall, int H, int32_t r2, uint8_t* moves) {
     int32_t rmin = r2 > 1 ? r2 : 1;
     int tk = sc_time_begin(ctx, SC_K_MOVES);
-    hipLaunchKernelGGL(moves_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, d2, W, H, rmin, moves);
+    hipLaunchKernelGGL(moves_kernel, dim3((W + 255) / 256, Hall), dim3(256), 0, ctx->stream, d2, W, Hall, H, rmin, moves);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -862,5 +864,5 @@ int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, ui
 extern "C" int sc_moves_i32_u8(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear, uint8_t* moves) {
     if (!ctx || !d2 || !moves || W <= 0 || H <= 0 || W > SC_MAX_DIM || H > SC_MAX_DIM) return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    return sc_launch_moves(ctx, d2, W, H, r2_clear, moves);
+    return sc_launch_moves(ctx, d2, W, H, H, r2_clear, moves);
 }

@@ -72,7 +72,7 @@ int sc_time_chain(sc_ctx* ctx, int token, int kid);
 
 // kernels' host launchers (defined in the respective .hip files)
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
-int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2, uint8_t* moves);
+int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int Hall, int H, int32_t r2, uint8_t* moves);   // Hall / H grids of H rows, stacked
 
 // wait for everything enqueued on the context's stream without burning a host core
 int sc_stream_wait(sc_ctx* ctx);

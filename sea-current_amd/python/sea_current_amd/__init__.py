@@ -54,6 +54,7 @@ _SIGNATURES = {
     "sc_edt_u8_i32_host": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sc_moves_i32_u8": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp]),
     "sc_astar_batch": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sc_astar_batch_multi": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_astar_batch_host": (_i, [_vp, _vp, _i, _i, C.c_int32, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sc_astar_last_expansions": (_i, [_vp, _i64p]),
     "sc_astar_debug_stats": (_i, [_vp, _vp, _i]),
@@ -208,6 +209,19 @@ class Context:
         self._ck(self._l.sc_astar_batch(self._h, _ptr(d2), W, H, r2, _ptr(start), _ptr(goal), Q, Lmax,
                                         _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]), _ptr(out["status"])),
                  "sc_astar_batch")
+        return out
+
+    def astar_batch_multi(self, d2, qgrid, start, goal, r2=0, Lmax=4096, out=None):
+        """Several grids in one launch: d2 int32 [G,H,W], qgrid int32 [Q] (grid of every query), start/goal int32 [Q]."""
+        import torch
+        G, H, W = d2.shape
+        Q = start.shape[0]
+        dev = d2.device
+        if out is None:
+            out = dict(path=torch.empty((Q, Lmax), dtype=torch.int32, device=dev), len=torch.empty(Q, dtype=torch.int32, device=dev),
+                       cost=torch.empty(Q, dtype=torch.int32, device=dev), status=torch.empty(Q, dtype=torch.int32, device=dev))
+        self._ck(self._l.sc_astar_batch_multi(self._h, _ptr(d2), G, _ptr(qgrid), W, H, r2, _ptr(start), _ptr(goal), Q, Lmax,
+                                              _ptr(out["path"]), _ptr(out["len"]), _ptr(out["cost"]), _ptr(out["status"])), "sc_astar_batch_multi")
         return out
 
     # ---- multi-GPU gather (RCCL through the C ABI) ----

@@ -94,7 +94,7 @@ def test_astar_truncated_and_lmax(ctx, oracle):
 def test_astar_1024_bench_config(ctx, oracle):
     """BASELINE configs[1] at full size on all three synthetic maps (first 96 queries vs the oracle)."""
     from sea_current_amd import synth
-    for occ in (synth.salt_grid(1024, 1024, 0.05), synth.block_grid(1024, 1024, 0.2)):
+    for occ in (synth.salt_grid(1024, 1024, 0.05), synth.salt_grid(1024, 1024, 0.20), synth.block_grid(1024, 1024, 0.2)):
         d2 = oracle.edt(occ)
         s, g = synth.queries(d2 >= 1, 96)
         ref = oracle.astar_batch(d2, s, g, Lmax=4096, nthreads=8)
@@ -127,3 +127,28 @@ def test_astar_4096_config3(ctx, oracle):
     ref = oracle.astar_batch(d2h, s, g, Lmax=16384, nthreads=16)
     _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 64)
     assert (ref["status"] == 0).all() and ref["len"].max() > 2048
+
+
+def test_astar_multi_grid_launch(ctx, oracle):
+    """sc_astar_batch_multi: three different grids (and clearances are per call) in one launch, every query against the
+    oracle on its own grid."""
+    import torch
+    from sea_current_amd import synth
+    W = H = 192
+    occs = [synth.salt_grid(W, H, 0.2, seed=21), synth.block_grid(W, H, 0.2, seed=22, smin=3, smax=20), synth.salt_grid(W, H, 0.05, seed=23)]
+    d2s = [oracle.edt(o) for o in occs]
+    ss, gs, qg = [], [], []
+    for k, d2 in enumerate(d2s):
+        s, g = synth.queries(d2 >= 1, 40 + 8 * k, seed=30 + k)
+        ss.append(s); gs.append(g); qg.append(np.full(s.shape[0], k, np.int32))
+    s, g, qgrid = np.concatenate(ss), np.concatenate(gs), np.concatenate(qg)
+    perm = np.random.default_rng(1).permutation(s.shape[0])          # queries of the grids interleaved
+    s, g, qgrid = s[perm], g[perm], qgrid[perm]
+    out = ctx.astar_batch_multi(torch.from_numpy(np.stack(d2s)).cuda(), torch.from_numpy(qgrid).cuda(), torch.from_numpy(s).cuda(),
+                                torch.from_numpy(g).cuda(), Lmax=2048)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for k, d2 in enumerate(d2s):
+        sel = np.flatnonzero(qgrid == k)
+        ref = oracle.astar_batch(d2, s[sel], g[sel], Lmax=2048, nthreads=4)
+        _compare({kk: vv[sel] for kk, vv in got.items()}, ref, sel.shape[0])

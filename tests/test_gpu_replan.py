@@ -56,3 +56,36 @@ def test_occ_from_rects_base_layer_and_clipping():
     torch.cuda.synchronize()
     assert int(empty.sum()) == 0
     ctx.close()
+
+
+def test_replan_configs4_size(oracle):
+    """BASELINE configs[4] at its grid size and one GPU's share of a frame: 1024^2, 1024 queries per frame, two frames,
+    every query of both frames against the oracle (16 host threads: a few seconds)."""
+    import torch
+    import sea_current_amd as sc
+    from sea_current_amd import synth
+    W = H = 1024
+    ctx = sc.Context(0)
+    try:
+        rects = synth.block_rects(W, H)
+        occ_dev = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        s = g = None
+        for frame in range(2):
+            if frame:
+                rects = synth.move_rects(rects, frame, W, H)
+            ctx.occ_from_rects(torch.from_numpy(rects).cuda(), W, H, out=occ_dev)
+            d2 = ctx.edt(occ_dev)
+            d2_ref = oracle.edt(synth.raster_rects(rects, W, H))
+            if s is None:
+                s, g = synth.queries(d2_ref >= 1, 1024)
+            out = ctx.astar_batch(d2, torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), Lmax=4096)
+            torch.cuda.synchronize()
+            assert np.array_equal(d2.cpu().numpy(), d2_ref), frame
+            ref = oracle.astar_batch(d2_ref, s, g, Lmax=4096, nthreads=16)
+            got = {k: v.cpu().numpy() for k, v in out.items()}
+            assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["cost"], ref["cost"]) and np.array_equal(got["len"], ref["len"]), frame
+            for q in range(1024):
+                if ref["status"][q] == 0:
+                    assert np.array_equal(got["path"][q, :ref["len"][q]], ref["path"][q, :ref["len"][q]]), (frame, q)
+    finally:
+        ctx.close()
