@@ -66,6 +66,13 @@ extern "C" int sc_ctx_use_own_stream(sc_ctx* ctx) {
     return SC_OK;
 }
 
+int sc_allow_big_lds(sc_ctx* ctx, const void* kernel, int bytes) {
+    if (ctx->big_lds_done.count(kernel)) return SC_OK;
+    SC_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->big_lds_done.insert(kernel);
+    return SC_OK;
+}
+
 int sc_stream_wait(sc_ctx* ctx) {
     if (!ctx->wait_ev) SC_HIP(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
     SC_HIP(ctx, hipEventRecord(ctx->wait_ev, ctx->stream));

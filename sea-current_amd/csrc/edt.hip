@@ -699,11 +699,9 @@ template <int PPL, bool FULL>
 static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     constexpr int WP = 64 * PPL;
     const size_t lds = PPL == 16 ? (size_t)32 * WP + 8 * 1024 : (size_t)32 * WP + (size_t)8 * 64 * (PPL / 2 + 1) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_g8_kernel<PPL, FULL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_g8_kernel<PPL, FULL>), 160 * 1024);
+        if (r_ != SC_OK) return r_;
     }
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
@@ -726,11 +724,9 @@ static int launch_band(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int n
     constexpr int WP = 64 * PPL;
     constexpr int TRN = (64 * (G + 1) > WP / 2 ? 64 * (G + 1) : WP / 2);
     const size_t lds = (size_t)(2 * (WP + 64) + 4 * TRN) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_kernel<PPL, FULL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_kernel<PPL, FULL>), 160 * 1024);
+        if (r_ != SC_OK) return r_;
     }
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
@@ -751,11 +747,9 @@ static int launch_band_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, i
 static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, int32_t* flags) {
     const int tiles = (W + EDT_TILE_CORE - 1) / EDT_TILE_CORE;
     const size_t lds = (size_t)32 * 1024 + 8 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(edt_band_g8_kernel<16, true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_g8_kernel<16, true, true>), 160 * 1024);
+        if (r_ != SC_OK) return r_;
     }
     SC_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)batch * sizeof(int32_t), ctx->stream));
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);

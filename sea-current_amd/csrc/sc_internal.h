@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <set>
 #include <vector>
 
 #include "../../include/sea_current_hip.h"
@@ -50,6 +51,7 @@ struct sc_ctx {
     bool comm_owned = false;
     int comm_ranks = 0, comm_rank = 0;
     int64_t gather_bytes = 0;       // bytes every rank received in the last gather
+    std::set<const void*> big_lds_done;   // kernels whose dynamic-LDS limit this context has raised on its device
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
 };
 
@@ -73,6 +75,11 @@ int sc_time_chain(sc_ctx* ctx, int token, int kid);
 // kernels' host launchers (defined in the respective .hip files)
 int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int32_t* d2);
 int sc_launch_moves(sc_ctx* ctx, const int32_t* d2, int W, int Hall, int H, int32_t r2, uint8_t* moves);   // Hall / H grids of H rows, stacked
+
+// Raise a kernel's dynamic-LDS limit (> 64 KiB needs hipFuncSetAttribute, which is per DEVICE): once per context, i.e.
+// once per device and host thread -- a process-wide flag would leave a second GPU's copy of the kernel at the default
+// and be written by several threads at once.
+int sc_allow_big_lds(sc_ctx* ctx, const void* kernel, int bytes);
 
 // wait for everything enqueued on the context's stream without burning a host core
 int sc_stream_wait(sc_ctx* ctx);

@@ -353,11 +353,9 @@ extern "C" int sc_toppra_sample_batch(sc_ctx* ctx, int P, int dof, int N,
     SC_HIP(ctx, hipSetDevice(ctx->device));
     sample_args a{P, dof, N, max_len, p0, p1, v0, v1, x, t, dt, pos, vel, acc, times, length};
     const size_t lds = (size_t)5 * (N + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(toppra_sample_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
+    {
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(toppra_sample_kernel), 160 * 1024 - 64);
+        if (r_ != SC_OK) return r_;
     }
     int tk = sc_time_begin(ctx, SC_K_TOPPRA_SAMPLE);
     hipLaunchKernelGGL(toppra_sample_kernel, dim3((unsigned)(P * dof)), dim3(64), lds, ctx->stream, a);

@@ -134,3 +134,41 @@ def test_edt_wide_rows_windows_and_fallback(ctx, oracle, W, H):
     got = d2.cpu().numpy()
     for b in range(occ.shape[0]):
         assert np.array_equal(got[b], oracle.edt(occ[b])), b
+
+
+def test_two_contexts_two_threads_big_lds_kernels(oracle):
+    """Two contexts driven from two host threads at once through the kernels that need more than 64 KiB of dynamic LDS
+    (4096-wide rows: the windowed kernel and, on a map with wide open areas, the whole-row kernel behind it): the raised
+    LDS limit is per context, so neither depends on the other having run first."""
+    import threading
+    import torch
+    import sea_current_amd as sc
+    from sea_current_amd import synth
+    occs = [synth.block_grid(4096, 96, 0.2, seed=41), synth.salt_grid(4096, 96, 0.2, seed=42)]
+    refs = [oracle.edt(o) for o in occs]
+    res, errs = [None, None], []
+
+    def work(i):
+        try:
+            c = sc.Context(0, use_torch_stream=False)
+            d2 = c.edt(torch.from_numpy(occs[i]).cuda())
+            tp = None
+            if i == 0:   # TOPP-RA's kernel raises its limit too
+                pl = synth.toppra_plans(4, dof=16)
+                t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                tp = c.toppra(t(pl["p0"]), t(pl["p1"]), t(pl["v0"]), t(pl["v1"]), t(-pl["vlim"]), t(pl["vlim"]), t(-pl["alim"]), t(pl["alim"]), N=200)
+            c.synchronize()
+            res[i] = d2.cpu().numpy()
+            assert tp is None or int((tp["status"] >= 0).sum()) == 4
+            c.close()
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(res[i], refs[i]), i
