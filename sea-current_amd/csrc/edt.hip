@@ -388,15 +388,14 @@ __device__ __noinline__ uint32_t edt_gdist_global(const uint32_t* cb, int W, int
 }
 
 // TILED (rows wider than 1024, PPL == 16): a workgroup handles a window of 1024 columns of its band -- a core of
-// EDT_TILE_CORE columns plus EDT_TILE_HALO on either side.  After `it` cascade steps a core pixel has seen every site
-// within `it` columns, all of them inside the window, so the usual stopping rule holds as long as it <= EDT_TILE_HALO;
+// 1024 - 2 halo columns plus `halo` on either side.  After `it` cascade steps a core pixel has seen every site
+// within `it` columns, all of them inside the window, so the usual stopping rule holds as long as it <= halo;
 // only the core is tested and stored.  A row that needs more steps (or leaves the packed range) raises flags[grid] and
 // the whole-row kernel redoes that grid afterwards.
-#define EDT_TILE_HALO 32
-#define EDT_TILE_CORE (1024 - 2 * EDT_TILE_HALO)
+#define EDT_TILE_HALO_MIN 32   // the halo is a multiple of 16 (whole lanes) chosen per width: see launch_band_g8_tiled
 template <int PPL, bool FULL, bool TILED = false>
 __global__ void __launch_bounds__(512, 8)
-edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2, int tiles,
+edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2, int tiles, int halo,
                    int32_t* __restrict__ flags) {
     static_assert(PPL == 8 || PPL == 16, "g8 path: 8 or 16 pixels per lane");
     static_assert(!TILED || (PPL == 16 && FULL), "tiled windows are full 1024-column rows");
@@ -416,7 +415,8 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     const int tile = TILED ? (int)(vid % (unsigned)tiles) : 0;
     const unsigned bg = TILED ? vid / (unsigned)tiles : vid;
     const int b = (int)(bg % (unsigned)nb), g = (int)(bg / (unsigned)nb);
-    const int xw0 = TILED ? tile * EDT_TILE_CORE - EDT_TILE_HALO : 0;   // global column of the window's first pixel
+    const int tcore = 1024 - 2 * halo;                                  // columns a window stores
+    const int xw0 = TILED ? tile * tcore - halo : 0;                    // global column of the window's first pixel
     if (TILED && __hip_atomic_load(&flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // grid already given up
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
@@ -563,7 +563,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
         // row needed (rows of a band are alike), then runs every step for a while and every second / fourth step later.
         // When to test only affects how many surplus steps run, never the result.
         int it = 1;
-        constexpr int IT_MAX = TILED ? EDT_TILE_HALO : 256;
+        const int IT_MAX = TILED ? halo : 256;
         for (; it <= IT_MAX; ++it) {
             cascade_step(it);
             if (it < chk_from && !(TILED && it == IT_MAX)) continue;
@@ -573,7 +573,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                 // only core pixels that exist in the row count: lanes 2 .. 61, global column < W
                 m = 0;
                 const int nv = W - (xw0 + PPL * lane);
-                if (lane >= EDT_TILE_HALO / PPL && lane < 64 - EDT_TILE_HALO / PPL) {
+                if (lane >= halo / PPL && lane < 64 - halo / PPL) {
 #pragma unroll
                     for (int j = 0; j < HP; ++j) {
                         if (j < nv) m = max(m, P[j] & 0xFFFFu);
@@ -634,7 +634,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
                 }
                 if constexpr (TILED) {
                     const int xg = xw0 + x;   // global column; only the core of the window is stored
-                    if (x >= EDT_TILE_HALO && x < EDT_TILE_HALO + EDT_TILE_CORE) {
+                    if (x >= halo && x < halo + tcore) {
                         if (xg + 3 < W && (((uintptr_t)(out + xg)) & 15) == 0) EDT_STORE4(out + xg, v);
                         else {
                             if (xg < W) out[xg] = v.x;
@@ -706,7 +706,7 @@ static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, in
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_g8_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream,
-                       colbits, W, H, nb, d2, 1, (int32_t*)nullptr);
+                       colbits, W, H, nb, d2, 1, 0, (int32_t*)nullptr);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -745,7 +745,13 @@ static int launch_band_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, i
 
 // rows wider than 1024: windows of 1024 columns through the fast kernel; flags[grid] != 0 where it gave up
 static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, int32_t* flags) {
-    const int tiles = (W + EDT_TILE_CORE - 1) / EDT_TILE_CORE;
+    // As few windows as the minimal halo allows; then the halo as wide as that number of windows leaves room for (whole
+    // lanes of 16 pixels): at W = 4096 five windows either way, with a halo of 96 columns instead of 32 -- rows whose
+    // largest distance is below 96 (block-type maps: ~60) then settle inside the window instead of sending the whole
+    // grid to the whole-row kernel.
+    const int tiles = (W + (1024 - 2 * EDT_TILE_HALO_MIN) - 1) / (1024 - 2 * EDT_TILE_HALO_MIN);
+    int halo = ((1024 - (W + tiles - 1) / tiles) / 2) / 16 * 16;
+    if (halo < EDT_TILE_HALO_MIN) halo = EDT_TILE_HALO_MIN;
     const size_t lds = (size_t)32 * 1024 + 8 * 1024;
     {
         int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_g8_kernel<16, true, true>), 160 * 1024);
@@ -755,7 +761,7 @@ static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_g8_kernel<16, true, true>), dim3((unsigned)((size_t)nb * batch * tiles)), dim3(512), lds, ctx->stream,
-                       colbits, W, H, nb, d2, tiles, flags);
+                       colbits, W, H, nb, d2, tiles, halo, flags);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
