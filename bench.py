@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--group", type=int, default=0,
                     help="consecutive steps handed to the library as ONE call (EDT with batch = group, sc_astar_batch_multi over "
                          "group x queries): the launch then has one tail for `group` steps; 1 = one call per step; "
-                         "0 = min(16, steps / depth), so that every context gets the same number of calls whatever --steps is")
+                         "0 = min(16, steps / (2 depth)): every context gets (at least) two calls whatever --steps is, so that "
+                         "one call's tail overlaps the next call's start")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,6 +111,9 @@ def main():
     ctxs = [sc.Context(local_rank, use_torch_stream=False) for _ in range(depth_max)]
     ctx = ctxs[0]
     if use_gather:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)    # RCCL prints its version banner on stdout when a communicator is created: keep stdout for the JSON line
         for c in ctxs:   # one communicator per context, created in the same order on every rank
             if world > 1:
                 box = [sc.Context.comm_unique_id() if rank == 0 else None]
@@ -118,6 +122,8 @@ def main():
             else:
                 uid = sc.Context.comm_unique_id()
             c.comm_init(uid, world, rank)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     def fence():
         for c in ctxs:
@@ -223,7 +229,7 @@ def main():
         return res
 
     if args.group <= 0:
-        args.group = max(1, min(16, -(-args.steps // depth_max)))
+        args.group = max(1, min(16, -(-args.steps // (2 * depth_max))))
     main_run = run_map(args.map, args.steps, args.warmup, depth_max, group=args.group)
     seq_run = run_map(args.map, max(2, min(args.steps, 4)), 1, 1)                     # one call per step, one stream
     others = {} if args.only_main_map else {f: run_map(f, args.steps, 1, depth_max, group=args.group) for f in FAMILIES if f != args.map}

@@ -143,7 +143,7 @@ edt_band_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int3
     const unsigned nwg = gridDim.x, per = nwg >> 3;
     const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
-    if (flags && flags[g] == 0) return;   // second pass after the tiled kernel: only grids it gave up on
+    if (flags && flags[(size_t)g * nb + b] == 0) return;   // second pass after the windowed kernel: only the bands it gave up on
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
     // ---- phase 1: per column, nearest obstacle above / below the band (look-back over band words) ----
@@ -390,13 +390,13 @@ __device__ __noinline__ uint32_t edt_gdist_global(const uint32_t* cb, int W, int
 // TILED (rows wider than 1024, PPL == 16): a workgroup handles a window of 1024 columns of its band -- a core of
 // 1024 - 2 halo columns plus `halo` on either side.  After `it` cascade steps a core pixel has seen every site
 // within `it` columns, all of them inside the window, so the usual stopping rule holds as long as it <= halo;
-// only the core is tested and stored.  A row that needs more steps (or leaves the packed range) raises flags[grid] and
-// the whole-row kernel redoes that grid afterwards.
+// only the core is tested and stored.  A row that needs more steps (or leaves the packed range) raises its band's flag and
+// the whole-row kernel redoes that band afterwards.
 #define EDT_TILE_HALO_MIN 32   // the halo is a multiple of 16 (whole lanes) chosen per width: see launch_band_g8_tiled
 template <int PPL, bool FULL, bool TILED = false>
 __global__ void __launch_bounds__(512, 8)
 edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2, int tiles, int halo,
-                   int32_t* __restrict__ flags) {
+                   int32_t* __restrict__ flags, const int32_t* __restrict__ only) {
     static_assert(PPL == 8 || PPL == 16, "g8 path: 8 or 16 pixels per lane");
     static_assert(!TILED || (PPL == 16 && FULL), "tiled windows are full 1024-column rows");
     constexpr int WAVES = 8;
@@ -415,9 +415,9 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     const int tile = TILED ? (int)(vid % (unsigned)tiles) : 0;
     const unsigned bg = TILED ? vid / (unsigned)tiles : vid;
     const int b = (int)(bg % (unsigned)nb), g = (int)(bg / (unsigned)nb);
+    if (TILED && only && only[(size_t)g * nb + b] == 0) return;        // a later pass: only the bands an earlier one gave up on
     const int tcore = 1024 - 2 * halo;                                  // columns a window stores
     const int xw0 = TILED ? tile * tcore - halo : 0;                    // global column of the window's first pixel
-    if (TILED && __hip_atomic_load(&flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // grid already given up
     const uint32_t* cb = colbits + (size_t)g * nb * W;
 
 #ifdef EDT_ABLATE_PHASE1   // timing-only: no look-back / recurrence, constant distances
@@ -595,7 +595,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             }
             const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
             if (__ballot(m > thr) == 0) break;
-            if (!TILED && it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }
+            if (it >= 252 && __ballot(m >= TRUST) != 0) { saturated = true; break; }   // beyond what the clamped bytes can represent
         }
         if (TILED && it > IT_MAX) saturated = true;   // not settled within the halo: leave the grid to the whole-row kernel
         chk_from = max(2, min(it, TILED ? IT_MAX - 1 : 250) - 1);
@@ -654,7 +654,7 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
             }
             wave_lds_sync();
         } else if constexpr (TILED) {
-            if (lane == 0) flags[g] = 1;
+            if (lane == 0) flags[(size_t)g * nb + b] = 1;
         } else {
             // ---- 32-bit cascade with exact distances (very sparse rows) ----
             uint32_t V[PPL];
@@ -706,7 +706,7 @@ static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, in
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
     hipLaunchKernelGGL((edt_band_g8_kernel<PPL, FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream,
-                       colbits, W, H, nb, d2, 1, 0, (int32_t*)nullptr);
+                       colbits, W, H, nb, d2, 1, 0, (int32_t*)nullptr, (const int32_t*)nullptr);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -743,25 +743,25 @@ static int launch_band_ppl(sc_ctx* ctx, const uint32_t* colbits, int W, int H, i
                          : launch_band<PPL, false>(ctx, colbits, W, H, nb, batch, d2, flags);
 }
 
-// rows wider than 1024: windows of 1024 columns through the fast kernel; flags[grid] != 0 where it gave up
-static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, int32_t* flags) {
-    // As few windows as the minimal halo allows; then the halo as wide as that number of windows leaves room for (whole
-    // lanes of 16 pixels): at W = 4096 five windows either way, with a halo of 96 columns instead of 32 -- rows whose
-    // largest distance is below 96 (block-type maps: ~60) then settle inside the window instead of sending the whole
-    // grid to the whole-row kernel.
-    const int tiles = (W + (1024 - 2 * EDT_TILE_HALO_MIN) - 1) / (1024 - 2 * EDT_TILE_HALO_MIN);
-    int halo = ((1024 - (W + tiles - 1) / tiles) / 2) / 16 * 16;
-    if (halo < EDT_TILE_HALO_MIN) halo = EDT_TILE_HALO_MIN;
+// Rows wider than 1024: windows of 1024 columns through the fast kernel; flags[grid][band] != 0 where it gave up.
+// `halo` columns on either side of a window's core bound the cascade steps (= the largest distance) a row may need;
+// `only`: process just the bands an earlier pass flagged.
+static int launch_band_g8_tiled(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2, int halo, int32_t* flags,
+                                const int32_t* only, bool first) {
+    const int tiles = (W + (1024 - 2 * halo) - 1) / (1024 - 2 * halo);
     const size_t lds = (size_t)32 * 1024 + 8 * 1024;
     {
         int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_g8_kernel<16, true, true>), 160 * 1024);
         if (r_ != SC_OK) return r_;
     }
-    SC_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)batch * sizeof(int32_t), ctx->stream));
-    int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
-    ctx->edt_chain_token = -1;
+    SC_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)batch * nb * sizeof(int32_t), ctx->stream));
+    int tk = -1;
+    if (first) {
+        tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+        ctx->edt_chain_token = -1;
+    } else tk = sc_time_begin(ctx, SC_K_EDT_BAND);
     hipLaunchKernelGGL((edt_band_g8_kernel<16, true, true>), dim3((unsigned)((size_t)nb * batch * tiles)), dim3(512), lds, ctx->stream,
-                       colbits, W, H, nb, d2, tiles, halo, flags);
+                       colbits, W, H, nb, d2, tiles, halo, flags, only);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -802,11 +802,26 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
     const int32_t* flags = nullptr;
 #ifndef EDT_NO_G8
     {
-        r = sc_scratch_reserve(ctx, &ctx->edt_flags, (size_t)batch * sizeof(int32_t));
+        // Pass 1: as few windows as the minimal halo allows, with the halo as wide as that number of windows leaves room
+        // for (whole lanes of 16 pixels): at W = 4096 five windows either way, with a halo of 96 columns instead of 32.
+        // Pass 2, only for the bands in which some row needed more steps than that (block-type maps: a tenth of the bands
+        // at 4096^2): windows with a halo of 256 columns, which covers every distance the packed cascade can represent.
+        // Pass 3: the whole-row kernel for what is still open (grids so sparse that distances exceed 255).
+        r = sc_scratch_reserve(ctx, &ctx->edt_flags, (size_t)2 * batch * nb * sizeof(int32_t));
         if (r != SC_OK) return r;
-        r = launch_band_g8_tiled(ctx, colbits, W, H, nb, batch, d2, (int32_t*)ctx->edt_flags.p);
+        int32_t* f1 = (int32_t*)ctx->edt_flags.p;
+        int32_t* f2 = f1 + (size_t)batch * nb;
+        const int tiles = (W + (1024 - 2 * EDT_TILE_HALO_MIN) - 1) / (1024 - 2 * EDT_TILE_HALO_MIN);
+        int halo = ((1024 - (W + tiles - 1) / tiles) / 2) / 16 * 16;
+        if (halo < EDT_TILE_HALO_MIN) halo = EDT_TILE_HALO_MIN;
+        r = launch_band_g8_tiled(ctx, colbits, W, H, nb, batch, d2, halo, f1, nullptr, true);
         if (r != SC_OK) return r;
-        flags = (const int32_t*)ctx->edt_flags.p;
+        flags = f1;
+        if (halo < 256) {
+            r = launch_band_g8_tiled(ctx, colbits, W, H, nb, batch, d2, 256, f2, f1, false);
+            if (r != SC_OK) return r;
+            flags = f2;
+        }
     }
 #endif
     if (W <= 2048) return launch_band_ppl<32>(ctx, colbits, W, H, nb, batch, d2, flags);

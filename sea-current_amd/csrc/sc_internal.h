@@ -30,7 +30,7 @@ struct sc_ctx {
     int64_t t_n[SC_K_COUNT] = {0};
     // scratch (grow-only)
     sc_scratch colbits;     // EDT: uint32 [batch][nb][W]
-    sc_scratch edt_flags;   // EDT, rows wider than 1024: int32 [batch], != 0 where the windowed kernel gave a grid up
+    sc_scratch edt_flags;   // EDT, rows wider than 1024: int32 [2][batch][bands], != 0 where a windowed pass gave a band up
     sc_scratch moves;       // A*: uint8 [H][W]
     sc_scratch gslots;      // A*: uint32 [S][g cells] (4 x 4-cell tiles)
     sc_scratch closed;      // A*: uint32 [S][bitmap words] closed set, one bit per cell (32 x 16-cell tiles)

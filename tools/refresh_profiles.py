@@ -1,39 +1,41 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof/ (made by tools/refresh_profiles.sh on the GPU box) into the tracked summaries under profiles/."""
-import csv, json, os, shutil, sys
+"""Turn gpurun_out/prof/ (made by tools/refresh_profiles.sh on the GPU box) into the tracked summaries under profiles/.
+usage: python tools/refresh_profiles.py r02"""
+import csv, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+for f in ("bench_default", "bench_forced_dist", "bench_steps20"):
+    shutil.copy(os.path.join(src, f + ".json"), os.path.join(dst, f"{tag}_{f}.json"))
 shutil.copy(os.path.join(src, "bench_stats", "b_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "edt_stats", "e_kernel_stats.csv"), os.path.join(dst, f"{tag}_edt64_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "toppra_stats", "t_kernel_stats.csv"), os.path.join(dst, f"{tag}_toppra_kernel_stats.csv"))
+for d in sorted(os.listdir(src)):
+    m = re.match(r"edt_stats_(\d+)_(\w+)$", d)
+    if m:
+        shutil.copy(os.path.join(src, d, "e_kernel_stats.csv"), os.path.join(dst, f"{tag}_edt_{m.group(1)}_{m.group(2)}_kernel_stats.csv"))
 
 
-def per_kernel(path, counter):
+def per_dispatch(path, counter, kernel_sub):
+    """counter value per dispatch (summed over the XCDs / instances of a dispatch) of kernels whose name contains kernel_sub"""
     acc = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
+        if r["Counter_Name"] != counter or kernel_sub not in r["Kernel_Name"]:
             continue
-        k = (r["Kernel_Name"].split("(")[0], r["Dispatch_Id"])
-        acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
-    out = {}
-    for (name, _), v in acc.items():
-        out.setdefault(name, []).append(v)
-    return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+        acc[r["Dispatch_Id"]] = acc.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return list(acc.values())
 
 
-rows = []
+# ---- EDT traffic (roofline.traffic) ----
 raw = {}
 for counter, d in (("FETCH_SIZE", "edt_fetch"), ("WRITE_SIZE", "edt_write")):
-    pk = per_kernel(os.path.join(src, d, "e_counter_collection.csv"), counter)
+    path = os.path.join(src, d, "e_counter_collection.csv")
     with open(os.path.join(dst, f"{tag}_edt64_pmc_{counter.lower()}.csv"), "w") as f:
         f.write("kernel,counter,mean_KB_per_dispatch,dispatches\n")
-        for k, (m, n) in sorted(pk.items()):
-            f.write(f"{k},{counter},{m:.3f},{n}\n")
-            short = "colbits" if "colbits" in k else "band" if "band" in k else None
-            if short:
-                raw[f"{short}_{counter}"] = m
+        for short, sub in (("colbits", "edt_colbits"), ("band", "edt_band")):
+            v = per_dispatch(path, counter, sub)
+            raw[f"{short}_{counter}"] = sum(v) / len(v)
+            f.write(f"{sub},{counter},{raw[short + '_' + counter]:.3f},{len(v)}\n")
 total = int((2 * raw["colbits_FETCH_SIZE"] + raw["colbits_WRITE_SIZE"] + raw["band_FETCH_SIZE"] + raw["band_WRITE_SIZE"]) * 1024)
 json.dump({"salt20": {
     "hbm_bytes_per_launch": total, "raw_KB": raw,
@@ -43,6 +45,59 @@ json.dump({"salt20": {
                    "neighbouring bands and Infinity-Cache hits). WRITE_SIZE exact (8 MiB and 256 MiB).",
     "algorithmic_bytes_per_launch": 5 * 64 * 1024 * 1024,
     "workload": "EDT of 64 x 1024x1024 salt20 grids (tools/edt_variants.py)"}}, open(os.path.join(dst, "edt_traffic.json"), "w"), indent=1)
-print("traffic bytes per launch:", total, raw)
-for r in csv.DictReader(open(os.path.join(dst, f"{tag}_edt64_kernel_stats.csv"))):
-    print(r["Name"][:60], r["Calls"], r["AverageNs"])
+print("EDT traffic bytes per launch:", total, raw)
+
+# ---- A* at saturation: 4096 copies of one query in one launch ----
+log = open(os.path.join(src, "astar_FETCH_SIZE.log")).read()
+m = re.search(r"x4096: ([\d.]+) ms, (\d+) expansions / (\d+) popped / (\d+) steps each -> ([\d.]+) G", log)
+ms, ex, pop, steps, gexp = float(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
+copies = 4096
+astar = {"workload": "4096 copies of one salt20 query (tools/astar_saturation.py salt20 4096) in one launch: the chip is full and there is no tail",
+         "expansions_per_query": ex, "popped_per_query": pop, "steps_per_query": steps, "launch_ms_under_profiler": ms,
+         "G_expansions_per_s_under_profiler": gexp}
+
+
+def top3(d, counter):
+    v = sorted(per_dispatch(os.path.join(src, d, "a_counter_collection.csv"), counter, "astar_kernel"), reverse=True)[:3]
+    return sum(v) / len(v)
+
+
+c = {}
+for d, names in (("astar_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_WAVE_CYCLES", ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES")),
+                 ("astar_SQ_INSTS_LDS_SQ_INSTS_VMEM_RD_SQ_INSTS_VMEM_WR", ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")),
+                 ("astar_TCC_ATOMIC_sum", ("TCC_ATOMIC_sum",)), ("astar_TCC_HIT_sum_TCC_MISS_sum", ("TCC_HIT_sum", "TCC_MISS_sum")),
+                 ("astar_FETCH_SIZE", ("FETCH_SIZE",)), ("astar_WRITE_SIZE", ("WRITE_SIZE",))):
+    for n in names:
+        c[n] = top3(d, n)
+nsteps = copies * steps
+nexp = copies * ex
+astar["counters_per_launch"] = c
+astar["per_step"] = {k: c[k] / nsteps for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
+astar["per_step"]["wave_cycles_x4"] = 4 * c["SQ_WAVE_CYCLES"] / nsteps
+astar["L2_atomic_requests_per_expansion"] = c["TCC_ATOMIC_sum"] / nexp
+astar["L2_miss_fraction"] = c["TCC_MISS_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+astar["HBM_GBps_fetch_plus_write_raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / (ms * 1e-3) / 1e9
+astar["round1_same_workload"] = {"L2_atomic_requests_per_expansion": 1.28, "L2_miss_fraction": 0.56, "cycles_per_step_alone": 2830,
+                                 "G_expansions_per_s": "8.5-9.7", "source": "profiles/r01_astar_saturation_pmc.json"}
+json.dump(astar, open(os.path.join(dst, f"{tag}_astar_saturation_pmc.json"), "w"), indent=1)
+print("A*:", json.dumps({k: v for k, v in astar.items() if k not in ("counters_per_launch", "workload")}, indent=1))
+
+# ---- TOPP-RA instruction counts ----
+tp = {}
+path = os.path.join(src, "toppra_pmc", "t_counter_collection.csv")
+for kern in ("toppra_kernel", "toppra_sample_kernel"):
+    tp[kern] = {}
+    for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES"):
+        v = per_dispatch(path, n, kern + "<" if kern == "toppra_kernel" else kern)
+        tp[kern][n + "_per_launch"] = sum(v) / len(v)
+    tp[kern]["per_plan"] = {n: tp[kern][n + "_per_launch"] / 1024 for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU")}
+    tp[kern]["wave_cycles_x4_per_plan"] = 4 * tp[kern]["SQ_WAVE_CYCLES_per_launch"] / 1024
+tp["workload"] = "1024 plans, 6 joints, 200 stages (tools/toppra_one.py); one wavefront per plan: per-plan = per-wave; a sweep is 400 dependent stages"
+tp["toppra_kernel"]["VALU_per_stage"] = tp["toppra_kernel"]["per_plan"]["SQ_INSTS_VALU"] / 400
+json.dump(tp, open(os.path.join(dst, f"{tag}_toppra_pmc.json"), "w"), indent=1)
+print("TOPP-RA:", json.dumps(tp, indent=1))
+for f in sorted(os.listdir(dst)):
+    if f.startswith(tag) and f.endswith("kernel_stats.csv") and "edt" in f:
+        for r in csv.DictReader(open(os.path.join(dst, f))):
+            if "edt" in r["Name"]:
+                print(f, r["Name"][:48], r["Calls"], r["AverageNs"])
