@@ -72,8 +72,8 @@ def main():
     ap.add_argument("--group", type=int, default=0,
                     help="consecutive steps handed to the library as ONE call (EDT with batch = group, sc_astar_batch_multi over "
                          "group x queries): the launch then has one tail for `group` steps; 1 = one call per step; "
-                         "0 = min(16, steps / (2 depth)): every context gets (at least) two calls whatever --steps is, so that "
-                         "one call's tail overlaps the next call's start")
+                         "0 = the largest divisor of --steps that is <= 16 and leaves every context at least one call "
+                         "(20 steps: 10 per call; 64 steps: 16 per call), so that exactly --steps steps are timed")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +188,7 @@ def main():
                         tp_last[0] = (tp, c.toppra_sample(tp_args[0], tp_args[1], tp_args[2], tp_args[3], tp["x"], tp["t"], 0.02, 512))
                         keep.append(tp_last[0])
 
-        steps = ((steps + G - 1) // G) * G              # whole groups: K is rounded up to a multiple of the group (reported)
+        steps = ((steps + G - 1) // G) * G              # whole groups (the default group divides --steps; an explicit --group may round K up: reported)
         run_steps(((max(warmup, depth * G) + G - 1) // G) * G)   # every context allocates its scratch on its first call: not timed
         fence()
         keep.clear()
@@ -229,7 +229,9 @@ def main():
         return res
 
     if args.group <= 0:
-        args.group = max(1, min(16, -(-args.steps // (2 * depth_max))))
+        divs = [g for g in range(1, 17) if args.steps % g == 0]
+        good = [g for g in divs if args.steps // g >= depth_max]
+        args.group = max(good) if good else max(divs)
     main_run = run_map(args.map, args.steps, args.warmup, depth_max, group=args.group)
     seq_run = run_map(args.map, max(2, min(args.steps, 4)), 1, 1)                     # one call per step, one stream
     others = {} if args.only_main_map else {f: run_map(f, args.steps, 1, depth_max, group=args.group) for f in FAMILIES if f != args.map}
