@@ -76,6 +76,7 @@ __device__ __forceinline__ double row16_minmax(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- the wide kernel (dof > 7: more rows than a row of 16 lanes holds) ----------------------------------------------
 // The sweeps are chains of N dependent stages, and a lone wavefront pays every instruction of a stage in full
 // (~5 cycles each), so what matters is how few instructions sit ON the chain.  Of a stage's rows only two -- the next
 // controllable set [K_lo, K_hi] in the backward pass, the state x in the forward pass -- depend on the previous stage:
@@ -90,7 +91,7 @@ __device__ __forceinline__ double row16_minmax(double v) {
 // A joint contributes two "slots" per stage (collocation at s_i; interpolation: the stage-(i+1) rows expressed at stage
 // i), each a pair of rows  +(a u + b x) <= ahi,  -(a u + b x) <= -alo : for a > 0 the first is the upper row.
 template <bool LDSLIM>
-__global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
+__global__ void __launch_bounds__(64) toppra_wide_kernel(toppra_args a) {
     __shared__ double s_c1[TP_MAXDOF], s_c2[TP_MAXDOF], s_c3[TP_MAXDOF];
     __shared__ double s_alo[TP_MAXDOF], s_ahi[TP_MAXDOF];
     extern __shared__ double s_dyn[];   // slo [N+1], shi [N+1], gridpoints [N+2], then K [N+1][2] sharing its place with the slots a / b [32][2 dof]
@@ -272,6 +273,357 @@ __global__ void __launch_bounds__(64) toppra_kernel(toppra_args a) {
     if (lane == 0) a.status[p] = status;
 }
 
+// ---- the fast kernel (dof <= 7) ---------------------------------------------------------------------------------------
+// Three wavefronts per plan, in lock step of chunks of TF_CH stages (one barrier per chunk):
+//   wave 0  the two dependent chains.  A stage's bounds are quotients (A k - T) / C with k the next set's K_hi or K_lo
+//           (backward) or (G - B x) / A (forward): the coefficients are waiting in LDS with the reciprocal of the divisor,
+//           so a quotient is two multiply-adds behind the product (the tail of the compiler's own fp64 division, without
+//           its scaling steps).  Lanes 0..15 hold what bounds from above, lanes 16..31 the NEGATED lower bounds, so ONE
+//           4-step DPP minimum inside the rows of 16 lanes yields both ends of the interval (lanes 0 and 16).
+//   wave 1  backward: the x-interval the acceleration rows leave among themselves (4 dof^2 pairs per stage, one lane per
+//           (stage, upper slot), a 16-lane reduction); forward: the stage coefficients;
+//   wave 2  the Hermite slots (a, b) of a chunk two steps ahead, and the backward coefficients one step ahead.
+// Bounds that do not apply are the constant 1e300 (every real bound is <= 1e16).  A divisor that is exactly zero (the
+// row pair bounds nothing but can declare the stage infeasible) raises a per-chunk flag, and wave 0 then evaluates that
+// rule as the wide kernel below does.  Quotients differ from IEEE division by at most one unit in the last place.
+#define TF_CH 4
+#define TF_THREADS 192
+#define TF_BIG 1e300
+
+__device__ __forceinline__ double fast_rcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+}
+// a / b given r = fast_rcp(b)
+__device__ __forceinline__ double div_by(double a, double b, double r) {
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-q, b, a), r, q);
+}
+// minimum / maximum inside each row of 16 lanes, left in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ double dpp_all_f64(double v) {     // every lane has a source lane: no previous value to keep
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ double row16_all(double v) {
+    auto op = [](double a, double b) { return IS_MIN ? dmin(a, b) : dmax(a, b); };
+    v = op(v, dpp_all_f64<0xB1>(v));
+    v = op(v, dpp_all_f64<0x4E>(v));
+    v = op(v, dpp_all_f64<0x141>(v));
+    v = op(v, dpp_all_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int DOF>
+__global__ void __launch_bounds__(TF_THREADS) toppra_fast_kernel(toppra_args a) {
+    __shared__ double s_c1[8], s_c2[8], s_c3[8], s_alo[8], s_ahi[8];
+    __shared__ int s_zf[2], s_out[3];
+    extern __shared__ __align__(16) double s_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, p = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int dof = DOF, ns = 2 * DOF;
+    const int N = a.N, n1 = N + 1;
+    double* s_slo = s_dyn;                       // [n1] static x-interval of a stage; after the backward pass: x
+    double* s_shi = s_slo + n1;                  // [n1]                                                        u
+    double* s_tab = s_shi + n1;                  // [n1 + 2] gridpoints i / N (and one spare: what follows stays 16-byte aligned)
+    double* s_K = s_tab + n1 + 2;                // [n1][2]
+    double* s_term = s_K + 2 * n1;               // [n1] knot time increments
+    double* s_slot = s_term + n1;                // [2][TF_CH][ns][6]   slots: a, b, and the slot's lower row (alpha, beta, gamma), one spare
+    double2* s_ent = reinterpret_cast<double2*>(s_slot + 12 * TF_CH * ns);   // [2][TF_CH][4][32] coefficient pairs
+    auto ent = [&](int b, int j, int f, int l) { return s_ent + (((b * TF_CH + j) * 4 + f) * 32 + l); };
+
+    for (int i = tid; i <= N + 1; i += TF_THREADS) s_tab[i] = (double)i / N;
+    if (tid < dof) {
+        const size_t o = (size_t)p * dof + tid;
+        s_alo[tid] = a.alo[o]; s_ahi[tid] = a.ahi[o];
+        const double d = a.p1[o] - a.p0[o], v0 = a.v0[o], v1 = a.v1[o];
+        s_c1[tid] = v0;
+        s_c2[tid] = 3.0 * d - 2.0 * v0 - v1;
+        s_c3[tid] = -2.0 * d + v0 + v1;
+    }
+    if (tid < 2) s_zf[tid] = 0;
+    for (int w = tid; w < 2 * TF_CH * 4 * 32; w += TF_THREADS) s_ent[w] = ((w >> 5) & 1) ? make_double2(1.0, 1.0) : make_double2(0.0, -TF_BIG);
+    __syncthreads();
+    double* K = a.K + (size_t)p * n1 * 2;
+    double* X = a.x + (size_t)p * n1;
+    double* U = a.u + (size_t)p * N;
+    double* T = a.t + (size_t)p * n1;
+
+    auto slot = [&](int i, int m, double& aa, double& bb) {
+        const int k = m >> 1;
+        const double s = s_tab[i], c1 = s_c1[k], c2 = s_c2[k], c3 = s_c3[k];
+        aa = c1 + s * (2.0 * c2 + s * 3.0 * c3); bb = 2.0 * c2 + 6.0 * c3 * s;
+        if ((m & 1) && i < N) {
+            const double s1 = s_tab[i + 1], D = s1 - s;
+            const double an = c1 + s1 * (2.0 * c2 + s1 * 3.0 * c3), bn = 2.0 * c2 + 6.0 * c3 * s1;
+            aa = an + 2.0 * D * bn;
+            bb = bn;
+        }
+    };
+    // slots of the stages i_of(j), j < TF_CH, into slot buffer b
+    auto fill_slots = [&](int b, auto i_of) {
+        for (int w = lane; w < TF_CH * ns; w += 64) {
+            const int j = w / ns, m = w - j * ns, i = i_of(j);
+            if (i < 0 || i >= N) continue;
+            double aa, bb;
+            slot(i, m, aa, bb);
+            double* o = s_slot + ((b * TF_CH + j) * ns + m) * 6;
+            const int k = m >> 1;
+            const bool pos = aa > 0, live = aa != 0.0;
+            o[0] = aa; o[1] = bb;
+            // the slot's row with alpha < 0; all zero when alpha == 0 (such a row takes no part in the pair elimination:
+            // a zero row pairs to cf = 0, rhs = 0, which bounds nothing)
+            o[2] = live ? (pos ? -aa : aa) : 0.0; o[3] = live ? (pos ? -bb : bb) : 0.0; o[4] = live ? (pos ? -s_alo[k] : s_ahi[k]) : 0.0;
+        }
+    };
+
+    // ---- velocity constraint (LinearJointVelocity::computeParams), one thread per stage ----
+    for (int i = tid; i <= N; i += TF_THREADS) {
+        const double s = s_tab[i];
+        double sdmin = -TP_MAXSD, sdmax = TP_MAXSD;
+        for (int k = 0; k < dof; ++k) {
+            const double v = s_c1[k] + s * (2.0 * s_c2[k] + s * 3.0 * s_c3[k]);
+            const size_t o = a.vlim_per_stage ? ((size_t)p * n1 + i) * dof + k : (size_t)p * dof + k;
+            const double lo = a.vlo[o], hi = a.vhi[o];
+            if (v > 0) { sdmax = fmin(hi / v, sdmax); sdmin = fmax(lo / v, sdmin); }
+            else if (v < 0) { sdmax = fmin(lo / v, sdmax); sdmin = fmax(hi / v, sdmin); }
+        }
+        s_slo[i] = sdmin > 0 ? sdmin * sdmin : 0.0;
+        s_shi[i] = sdmax * sdmax;
+    }
+    __syncthreads();
+
+    const int nchunk = (N + TF_CH - 1) / TF_CH;
+    int status = 0, kfirst = N, nx = 0;              // wave 0's
+    double klo = a.sd_end * a.sd_end, khi = klo;
+    if (tid == 0) { s_K[2 * N] = klo; s_K[2 * N + 1] = khi; }
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+
+    // ================= backward: controllable sets, stages N-1 .. 0; chunk c holds stages N-1 - c TF_CH - j =================
+    for (int st = 0; st < nchunk + 2; ++st) {
+        if (wave == 2) {
+            if (st < nchunk) fill_slots(st & 1, [&](int j) { return N - 1 - st * TF_CH - j; });
+            if (st >= 1 && st <= nchunk) {
+                const int c = st - 1, b = c & 1;
+                bool zero = false;
+                for (int w = lane; w < TF_CH * ns; w += 64) {
+                    const int j = w / ns, m = w - j * ns, i = N - 1 - c * TF_CH - j;
+                    if (i < 0) continue;
+                    const double aa = s_slot[((b * TF_CH + j) * ns + m) * 6], bb = s_slot[((b * TF_CH + j) * ns + m) * 6 + 1];
+                    const int k = m >> 1;
+                    const double twoD = 2.0 * (s_tab[i + 1] - s_tab[i]);
+                    const bool pos = aa > 0, live = aa != 0.0;
+                    const double ali = pos ? aa : -aa, bei = pos ? bb : -bb, gai = pos ? s_ahi[k] : -s_alo[k];    // upper row of the slot
+                    const double alj = pos ? -aa : aa, bej = pos ? -bb : bb, gaj = pos ? -s_alo[k] : s_ahi[k];   // lower row
+                    // upper = (2D, 1, khi) of the next set, lower = this slot's:  v1 = (alj khi - 2D gaj) / cf1
+                    const double cf1 = alj * 1.0 - twoD * bej, t1 = twoD * gaj, r1 = fast_rcp(cf1);
+                    // upper = this slot's, lower = (-2D, -1, -klo) of the next set:  v2 = ((-2D) gai + ali klo) / cf2
+                    const double cf2 = (-twoD) * bei - ali * (-1.0), t2 = (-twoD) * gai, r2 = fast_rcp(cf2);
+                    zero = zero || (live && (cf1 == 0.0 || cf2 == 0.0));
+                    const double2 nnum = make_double2(0.0, -TF_BIG), nden = make_double2(1.0, 1.0);
+                    // cf < 0: the quotient bounds x from above (row 0); cf > 0: from below (row 1, negated numerator)
+                    *ent(b, j, 0, m) = live && cf1 < 0 ? make_double2(alj, t1) : nnum;
+                    *ent(b, j, 1, m) = live && cf1 < 0 ? make_double2(cf1, r1) : nden;
+                    *ent(b, j, 0, 16 + m) = live && cf1 > 0 ? make_double2(-alj, -t1) : nnum;
+                    *ent(b, j, 1, 16 + m) = live && cf1 > 0 ? make_double2(cf1, r1) : nden;
+                    *ent(b, j, 2, m) = live && cf2 < 0 ? make_double2(ali, -t2) : nnum;
+                    *ent(b, j, 3, m) = live && cf2 < 0 ? make_double2(cf2, r2) : nden;
+                    *ent(b, j, 2, 16 + m) = live && cf2 > 0 ? make_double2(-ali, t2) : nnum;
+                    *ent(b, j, 3, 16 + m) = live && cf2 > 0 ? make_double2(cf2, r2) : nden;
+                }
+                if (__ballot(zero) && lane == 0) s_zf[b] = 1;
+            }
+        } else if (wave == 1) {
+            if (st >= 1 && st <= nchunk) {
+                // the acceleration rows against each other: lane (j, mu) takes the upper row from slot mu, loops over the lower rows
+                const int c = st - 1, b = c & 1, j = lane >> 4, mu = lane & 15, i = N - 1 - c * TF_CH - j;
+                double lo = -INFINITY, hi = INFINITY;
+                bool bad = false;
+                if (mu < ns && i >= 0) {
+                    const double* sl = s_slot + (size_t)(b * TF_CH + j) * ns * 6;
+                    const double au = sl[6 * mu], bu = sl[6 * mu + 1];
+                    const int ku = mu >> 1;
+                    if (au == 0.0) {
+                        // alpha == 0: both rows of the slot bound x directly
+                        const double g0 = s_ahi[ku], g1 = -s_alo[ku];
+                        if (bu > 0) { hi = fmin(hi, g0 / bu); lo = fmax(lo, g1 / -bu); }
+                        else if (bu < 0) { lo = fmax(lo, g0 / bu); hi = fmin(hi, g1 / -bu); }
+                        else if (g0 < -TP_LP_TOL || g1 < -TP_LP_TOL) bad = true;
+                    } else {
+                        const double ali = au > 0 ? au : -au, bei = au > 0 ? bu : -bu, gai = au > 0 ? s_ahi[ku] : -s_alo[ku];
+#pragma unroll
+                        for (int ml = 0; ml < ns; ++ml) {
+                            const double alj = sl[6 * ml + 2], bej = sl[6 * ml + 3], gaj = sl[6 * ml + 4];
+                            const double cf = alj * bei - ali * bej, rhs = alj * gai - ali * gaj;
+                            const double v = div_by(rhs, cf, fast_rcp(cf));
+                            lo = dmax(lo, cf > 0 ? v : -INFINITY);
+                            hi = dmin(hi, cf < 0 ? v : INFINITY);
+                            bad = bad || (cf == 0.0 && rhs > TP_LP_TOL);
+                        }
+                    }
+                }
+                lo = row16_all<false>(lo); hi = row16_all<true>(hi);
+                const unsigned long long bm = __ballot(bad);
+                if (mu == 0 && i >= 0) {
+                    const bool anybad = (bm >> (16 * j)) & 0xFFFFull;
+                    s_slo[i] = anybad ? INFINITY : dmax(s_slo[i], lo);
+                    s_shi[i] = anybad ? -INFINITY : dmin(s_shi[i], hi);
+                }
+            }
+        } else if (st >= 2 && !status) {
+            const int c = st - 2, b = c & 1, i0 = N - 1 - c * TF_CH, l32 = lane & 31;
+            // the static interval of each stage of the chunk, as the constant "quotients" (0 k + shi) / 1 and (0 k - slo) / 1
+            if (lane < 2 * TF_CH) {
+                const int j = lane >> 1, r = lane & 1, i = i0 - j;
+                if (i >= 0) *ent(b, j, 0, 16 * r + ns) = make_double2(0.0, r ? s_slo[i] : -s_shi[i]);
+            }
+            const int zf = s_zf[b];
+            if (zf && lane == 0) s_zf[b] = 0;
+            double2 f[TF_CH][4];
+            double twoD[TF_CH];
+#pragma unroll
+            for (int j = 0; j < TF_CH; ++j) {
+                const int i = i0 - j > 0 ? i0 - j : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[j][q] = *ent(b, j, q, l32);
+                twoD[j] = 2.0 * (s_tab[i + 1] - s_tab[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TF_CH; ++j) {
+                const int i = i0 - j;
+                if (i < 0 || status) continue;
+                const double v1 = div_by(f[j][0].x * khi - f[j][0].y, f[j][1].x, f[j][1].y);
+                const double v2 = div_by(f[j][2].x * klo - f[j][2].y, f[j][3].x, f[j][3].y);
+                const double w = row16_all<true>(dmin(v1, v2));
+                double hi = lane_f64(w, 0), lo = -lane_f64(w, 16);
+                bool infeasible = (-twoD[j]) * khi - twoD[j] * (-klo) > TP_LP_TOL;      // the next set against itself
+                if (zf) {
+                    // a row pair with a zero divisor somewhere in this chunk: the rule of the wide kernel, lanes over slots
+                    double aa, bb;
+                    slot(i, lane < ns ? lane : 0, aa, bb);
+                    const int k = lane < ns ? lane >> 1 : 0;
+                    const bool pos = aa > 0, live = lane < ns && aa != 0.0;
+                    const double ali = pos ? aa : -aa, bei = pos ? bb : -bb, gai = pos ? s_ahi[k] : -s_alo[k];
+                    const double alj = pos ? -aa : aa, bej = pos ? -bb : bb, gaj = pos ? -s_alo[k] : s_ahi[k];
+                    const double cf1 = alj * 1.0 - twoD[j] * bej, rhs1 = alj * khi - twoD[j] * gaj;
+                    const double cf2 = (-twoD[j]) * bei - ali * (-1.0), rhs2 = (-twoD[j]) * gai - ali * (-klo);
+                    if (__ballot(live && ((cf1 == 0.0 && rhs1 > TP_LP_TOL) || (cf2 == 0.0 && rhs2 > TP_LP_TOL)))) infeasible = true;
+                }
+                if (infeasible || lo > hi + TP_LP_TOL) { status = 1; continue; }
+                if (lo > hi) lo = hi;
+                klo = lo > 0 ? lo : 0.0;
+                khi = hi;
+                kfirst = i;
+                if (lane == 0) { s_K[2 * i] = klo; s_K[2 * i + 1] = khi; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================= forward: greedy maximal u; chunk c holds stages c TF_CH + j =================
+    double x = a.sd_start * a.sd_start;
+    if (wave == 0) {
+        if (!status) {
+            if (x < klo - TP_LP_TOL || x > khi + TP_LP_TOL) status = 2;
+            nx = 1;
+        }
+        if (lane == 0) s_out[0] = status;
+    }
+    // bounds that do not apply, forward form: (1e300 - 0 x) / 1
+    for (int w = tid; w < 2 * TF_CH * 4 * 32; w += TF_THREADS)
+        if (((w >> 5) & 3) < 2) s_ent[w] = ((w >> 5) & 1) ? make_double2(1.0, 1.0) : make_double2(TF_BIG, 0.0);
+    __syncthreads();
+    const bool run_forward = s_out[0] == 0;           // the same for every wave
+    if (wave == 0 && lane == 0) s_slo[0] = x;
+    for (int st = 0; run_forward && st < nchunk + 2; ++st) {
+        if (wave == 2) {
+            if (st < nchunk) fill_slots(st & 1, [&](int j) { return st * TF_CH + j; });
+        } else if (wave == 1) {
+            if (st >= 1 && st <= nchunk) {
+                const int c = st - 1, b = c & 1;
+                for (int w = lane; w < TF_CH * (ns + 1); w += 64) {
+                    const int j = w / (ns + 1), m = w - j * (ns + 1), i = c * TF_CH + j;
+                    if (i >= N) continue;
+                    double2 g0 = make_double2(TF_BIG, 0.0), g1 = g0, d0 = make_double2(1.0, 1.0), d1 = d0;
+                    if (m == ns) {
+                        // the rows of the next set:  u <= (nhi - x) / 2D,  -u <= (nlo - x) / (-2D)
+                        const double twoD = 2.0 * (s_tab[i + 1] - s_tab[i]);
+                        const double nlo = s_K[2 * (i + 1)], nhi = s_K[2 * (i + 1) + 1];
+                        g0 = make_double2(nhi, 1.0); d0 = make_double2(twoD, fast_rcp(twoD));
+                        g1 = make_double2(nlo, 1.0); d1 = make_double2(-twoD, fast_rcp(-twoD));
+                    } else {
+                        const double aa = s_slot[((b * TF_CH + j) * ns + m) * 6], bb = s_slot[((b * TF_CH + j) * ns + m) * 6 + 1];
+                        const int k = m >> 1;
+                        if (aa != 0.0) {
+                            // rows (aa, bb, ahi) and (-aa, -bb, -alo): the one with alpha > 0 bounds u from above, the other from below
+                            const double rp = fast_rcp(aa), rn = fast_rcp(-aa), ahi = s_ahi[k], alo = s_alo[k];
+                            if (aa > 0) { g0 = make_double2(ahi, bb); d0 = make_double2(aa, rp); g1 = make_double2(alo, bb); d1 = make_double2(-aa, rn); }
+                            else { g0 = make_double2(-alo, -bb); d0 = make_double2(-aa, rn); g1 = make_double2(-ahi, -bb); d1 = make_double2(aa, rp); }
+                        }
+                    }
+                    *ent(b, j, 0, m) = g0; *ent(b, j, 1, m) = d0;
+                    *ent(b, j, 0, 16 + m) = g1; *ent(b, j, 1, 16 + m) = d1;
+                }
+            }
+        } else if (st >= 2 && !status) {
+            const int c = st - 2, b = c & 1, i0 = c * TF_CH, l32 = lane & 31;
+            double2 f[TF_CH][2];
+            double twoD[TF_CH], nlo[TF_CH], nhi[TF_CH];
+#pragma unroll
+            for (int j = 0; j < TF_CH; ++j) {
+                const int i = i0 + j < N ? i0 + j : N - 1;
+                f[j][0] = *ent(b, j, 0, l32); f[j][1] = *ent(b, j, 1, l32);
+                twoD[j] = 2.0 * (s_tab[i + 1] - s_tab[i]);
+                nlo[j] = s_K[2 * (i + 1)]; nhi[j] = s_K[2 * (i + 1) + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < TF_CH; ++j) {
+                const int i = i0 + j;
+                if (i >= N || status) continue;
+                const double w = row16_all<true>(div_by(f[j][0].x - f[j][0].y * x, f[j][1].x, f[j][1].y));
+                const double umax = lane_f64(w, 0), umin = -lane_f64(w, 16);
+                if (!(umax >= umin - 1e-6) || !isfinite(umax)) { status = 2; continue; }
+                double xn = x + twoD[j] * umax;
+                if (xn > nhi[j]) xn = nhi[j];
+                if (xn < nlo[j]) xn = nlo[j];
+                if (lane == 0) { s_shi[i] = umax; s_slo[i + 1] = xn; }
+                x = xn;
+                nx = i + 2;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && lane == 0) { s_out[0] = status; s_out[1] = kfirst; s_out[2] = nx; }
+    __syncthreads();
+    // ================= results: K, x, u from LDS; knot times (a sequential sum, in the oracle's order) =================
+    status = s_out[0]; kfirst = s_out[1]; nx = s_out[2];
+    for (int i = kfirst + tid; i <= N; i += TF_THREADS) { K[2 * i] = s_K[2 * i]; K[2 * i + 1] = s_K[2 * i + 1]; }
+    for (int i = tid; i < nx; i += TF_THREADS) X[i] = s_slo[i];
+    for (int i = tid; i < nx - 1; i += TF_THREADS) {
+        U[i] = s_shi[i];
+        const double D = s_tab[i + 1] - s_tab[i];
+        const double sda = 0.5 * (sqrt(fmax(s_slo[i], 0.0)) + sqrt(fmax(s_slo[i + 1], 0.0)));
+        s_term[i] = sda > TP_NEARLY_ZERO ? D / sda : 5.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.status[p] = status;
+        if (nx > 0) {
+            double tt = 0.0;
+            T[0] = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < nx - 1; ++i) { tt += s_term[i]; T[i + 1] = tt; }
+        }
+    }
+}
+
 extern "C" int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
                                        const double* p0, const double* p1, const double* v0, const double* v1,
                                        const double* vlim_lo, const double* vlim_hi, int vlim_per_stage,
@@ -282,6 +634,20 @@ extern "C" int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
         !alim_lo || !alim_hi || !K || !x || !u || !t || !status)
         return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (dof <= 7) {
+        const size_t lds = ((size_t)6 * (N + 1) + 2 + (size_t)24 * TF_CH * dof) * sizeof(double) + (size_t)2 * TF_CH * 4 * 32 * sizeof(double2);
+        if (lds > 150 * 1024) { snprintf(ctx->err, sizeof(ctx->err), "sc_toppra_hermite_batch: N = %d stages do not fit the LDS of a CU", N); return SC_ERR_INVALID; }
+        toppra_args a{P, dof, N, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, vlim_per_stage, 0, sd_start, sd_end, K, x, u, t, status};
+        void (*kern)(toppra_args) = dof == 1 ? toppra_fast_kernel<1> : dof == 2 ? toppra_fast_kernel<2> : dof == 3 ? toppra_fast_kernel<3> :
+                                    dof == 4 ? toppra_fast_kernel<4> : dof == 5 ? toppra_fast_kernel<5> : dof == 6 ? toppra_fast_kernel<6> : toppra_fast_kernel<7>;
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(kern), 150 * 1024);
+        if (r_ != SC_OK) return r_;
+        int tk = sc_time_begin(ctx, SC_K_TOPPRA);
+        hipLaunchKernelGGL(kern, dim3(P), dim3(TF_THREADS), lds, ctx->stream, a);
+        sc_time_end(ctx, tk);
+        SC_HIP(ctx, hipGetLastError());
+        return SC_OK;
+    }
     const size_t kwords = (size_t)2 * (N + 1) > (size_t)128 * dof ? (size_t)2 * (N + 1) : (size_t)128 * dof;
     const size_t base = ((size_t)3 * (N + 1) + 1 + kwords) * sizeof(double);                          // static interval, gridpoints, K | slot chunk
     const size_t lim = (size_t)2 * (vlim_per_stage ? (N + 1) : 1) * dof * sizeof(double);
@@ -291,12 +657,12 @@ extern "C" int sc_toppra_hermite_batch(sc_ctx* ctx, int P, int dof, int N,
     toppra_args a{P, dof, N, p0, p1, v0, v1, vlim_lo, vlim_hi, alim_lo, alim_hi, vlim_per_stage, lds_limits,
                   sd_start, sd_end, K, x, u, t, status};
     {
-        int r_ = sc_allow_big_lds(ctx, lds_limits ? reinterpret_cast<const void*>(toppra_kernel<true>) : reinterpret_cast<const void*>(toppra_kernel<false>), 150 * 1024);
+        int r_ = sc_allow_big_lds(ctx, lds_limits ? reinterpret_cast<const void*>(toppra_wide_kernel<true>) : reinterpret_cast<const void*>(toppra_wide_kernel<false>), 150 * 1024);
         if (r_ != SC_OK) return r_;
     }
     int tk = sc_time_begin(ctx, SC_K_TOPPRA);
-    if (lds_limits) hipLaunchKernelGGL(toppra_kernel<true>, dim3(P), dim3(64), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(toppra_kernel<false>, dim3(P), dim3(64), lds, ctx->stream, a);
+    if (lds_limits) hipLaunchKernelGGL(toppra_wide_kernel<true>, dim3(P), dim3(64), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(toppra_wide_kernel<false>, dim3(P), dim3(64), lds, ctx->stream, a);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -312,62 +678,71 @@ struct sample_args {
     int32_t* length;
 };
 
-// One block (64 threads) per plan; dynamic LDS: (1 + 4 dof) * (N+1) doubles.  Lane k < dof solves joint k's clamped-spline
-// system (a chain of N dependent eliminations each, the joints side by side; one block per (plan, joint) with a single
-// busy lane each took 4x as long for the batch); then a lane takes a sample, finds its knot interval once and evaluates
-// every joint there.
-__global__ void __launch_bounds__(64) toppra_sample_kernel(sample_args a) {
-    extern __shared__ double sm[];
+// One block (256 threads) per plan; dynamic LDS: (2 + 3 dof)(N + 1) doubles + (N + 1) 16-bit knot indices.  All threads
+// pick the knots (ballot compaction), evaluate the joints' knot positions and chord slopes; then lane k < dof of the first
+// wavefront solves joint k's clamped-spline system (N dependent eliminations, the joints side by side; the pivots depend
+// on the knot times only and are shared); then a thread takes a sample, finds its knot interval once and evaluates every
+// joint there.  The eliminations and the per-sample cubic multiply by reciprocals (one division per pivot, one per
+// sample) where the oracle divides: results agree to a few units in the last place.
+#define TS_THREADS 256
+__global__ void __launch_bounds__(TS_THREADS) toppra_sample_kernel(sample_args a) {
+    extern __shared__ __align__(16) double sm[];
     const int N = a.N, n1 = N + 1, dof = a.dof;
     double* tk = sm;                       // [n1] knot times (zero increments dropped)
-    double* yk = tk + n1;                  // [dof][n1] joint positions at the knots
-    double* M = yk + (size_t)dof * n1;     // [dof][n1] second derivatives
-    double* cp = M + (size_t)dof * n1;     // [dof][n1] Thomas algorithm
-    double* dp = cp + (size_t)dof * n1;
-    __shared__ int s_n;
-    __shared__ int s_idx[4001];
-    const int lane = threadIdx.x, p = blockIdx.x;
+    double* cs = tk + n1;                  // [n1] Thomas algorithm: upper / pivot (the same for every joint)
+    double* yk = cs + n1;                  // [dof][n1] joint positions at the knots
+    double* M = yk + (size_t)dof * n1;     // [dof][n1] chord slopes, then second derivatives
+    double* dp = M + (size_t)dof * n1;     // [dof][n1] Thomas algorithm: right-hand sides
+    unsigned short* idx = reinterpret_cast<unsigned short*>(dp + (size_t)dof * n1);   // [n1] stage of each knot
+    __shared__ int s_cnt[TS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
     const double* t = a.t + (size_t)p * n1;
     const double* x = a.x + (size_t)p * n1;
-    if (lane == 0) {
-        // knots with a (nearly) zero time increment are dropped, as parametrizer::Spline does
-        int n = 0;
-        for (int i = 0; i <= N; ++i)
-            if (i == 0 || t[i] - t[i - 1] >= TP_NEARLY_ZERO) { tk[n] = t[i]; s_idx[n] = i; ++n; }
-        s_n = n;
+    // knots with a (nearly) zero time increment are dropped, as parametrizer::Spline does
+    int n = 0;
+    for (int base = 0; base <= N; base += TS_THREADS) {
+        const int i = base + tid;
+        double ti = 0;
+        bool keep = false;
+        if (i <= N) { ti = t[i]; keep = i == 0 || ti - t[i - 1] >= TP_NEARLY_ZERO; }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = n, tot = 0;
+        for (int w = 0; w < TS_THREADS / 64; ++w) { const int c = s_cnt[w]; if (w < wave) off += c; tot += c; }
+        if (keep) { const int r = off + __popcll(m & ((1ull << lane) - 1)); tk[r] = ti; idx[r] = (unsigned short)i; }
+        n += tot;
+        __syncthreads();
     }
-    __syncthreads();
-    const int n = s_n;
-    // knot positions of every joint: independent, all lanes (each an fp64 division for s: kept off the serial solves)
-    for (int w = lane; w < dof * n; w += 64) {
+    // knot positions of every joint (each an fp64 division for s: kept off the serial solves)
+    for (int w = tid; w < dof * n; w += TS_THREADS) {
         const int k = w / n, j = w - k * n;
         const size_t o = (size_t)p * dof + k;
         const double q0 = a.p0[o], c1 = a.v0[o], dd = a.p1[o] - q0;
         const double c2 = 3.0 * dd - 2.0 * c1 - a.v1[o], c3 = -2.0 * dd + c1 + a.v1[o];
-        const double s = (double)s_idx[j] / N;
+        const double s = (double)idx[j] / N;
         yk[(size_t)k * n1 + j] = q0 + s * (c1 + s * (c2 + s * c3));
     }
     __syncthreads();
-    // chord slopes (y[j+1] - y[j]) / (tk[j+1] - tk[j]): independent divisions, all lanes; parked in M, which the solves
-    // only write once their forward eliminations are through
-    for (int w = lane; w < dof * (n - 1); w += 64) {
+    // chord slopes (y[j+1] - y[j]) / (tk[j+1] - tk[j]), parked in M, which the solves only write in their back substitution
+    for (int w = tid; w < dof * (n - 1); w += TS_THREADS) {
         const int k = w / (n - 1), j = w - k * (n - 1);
         const double* y = yk + (size_t)k * n1;
         M[(size_t)k * n1 + j] = (y[j + 1] - y[j]) / (tk[j + 1] - tk[j]);
     }
     __syncthreads();
-    if (lane < dof) {
-        const int k = lane;
+    if (tid < dof) {
+        const int k = tid;
         const size_t o = (size_t)p * dof + k;
         const double q0 = a.p0[o], c1 = a.v0[o], dd = a.p1[o] - q0;
         const double c2 = 3.0 * dd - 2.0 * c1 - a.v1[o], c3 = -2.0 * dd + c1 + a.v1[o];
         double* Mk = M + (size_t)k * n1;
-        double* c = cp + (size_t)k * n1;
         double* d = dp + (size_t)k * n1;
         const double d0 = c1 * sqrt(fmax(x[0], 0.0));
         const double d1 = (c1 + 2.0 * c2 + 3.0 * c3) * sqrt(fmax(x[N], 0.0));
         if (n == 1) Mk[0] = 0.0;
         else {
+            double cprev = 0, dprev = 0;
             for (int j = 0; j < n; ++j) {
                 double lo, di, up, rhs;
                 if (j == 0) {
@@ -381,23 +756,23 @@ __global__ void __launch_bounds__(64) toppra_sample_kernel(sample_args a) {
                     lo = h0; di = 2 * (h0 + h1); up = h1;
                     rhs = 6 * (Mk[j] - Mk[j - 1]);
                 }
-                if (j == 0) { c[0] = up / di; d[0] = rhs / di; }
-                else {
-                    const double m = di - lo * c[j - 1];
-                    c[j] = up / m;
-                    d[j] = (rhs - lo * d[j - 1]) / m;
-                }
+                const double im = fast_rcp(di - lo * cprev);
+                cprev = up * im;
+                dprev = (rhs - lo * dprev) * im;
+                if (k == 0) cs[j] = cprev;
+                d[j] = dprev;
             }
-            Mk[n - 1] = d[n - 1];
-            for (int j = n - 2; j >= 0; --j) Mk[j] = d[j] - c[j] * Mk[j + 1];
+            double mn = dprev;
+            Mk[n - 1] = mn;
+            for (int j = n - 2; j >= 0; --j) { mn = d[j] - cs[j] * mn; Mk[j] = mn; }
         }
     }
     __syncthreads();
     const double T = tk[n - 1];
     const int length = (int)ceil(T / a.dt);
     const int wl = min(length, a.max_len);
-    if (lane == 0) a.length[p] = length;
-    for (int j = lane; j < wl; j += 64) {
+    if (tid == 0) a.length[p] = length;
+    for (int j = tid; j < wl; j += TS_THREADS) {
         const double tt = length > 1 ? (j == length - 1 ? T : (T * j) / (length - 1)) : 0.0;
         a.times[(size_t)p * a.max_len + j] = tt;
         int seg = 0;
@@ -410,17 +785,20 @@ __global__ void __launch_bounds__(64) toppra_sample_kernel(sample_args a) {
             }
             seg = lo;
         }
+        double h = 1, ih = 1, aa = 0, bb = 0;
+        if (n > 1) { h = tk[seg + 1] - tk[seg]; ih = 1.0 / h; aa = tk[seg + 1] - tt; bb = tt - tk[seg]; }
+        const double h6 = h * (1.0 / 6.0), i6h = ih * (1.0 / 6.0), i2h = 0.5 * ih;
         for (int k = 0; k < dof; ++k) {
             const double* y = yk + (size_t)k * n1;
             const double* Mk = M + (size_t)k * n1;
             double P_, V_, A_;
             if (n == 1) { P_ = y[0]; V_ = 0; A_ = 0; }
             else {
-                const double h = tk[seg + 1] - tk[seg], aa = tk[seg + 1] - tt, bb = tt - tk[seg];
-                const double ca = y[seg] / h - Mk[seg] * h / 6, cb = y[seg + 1] / h - Mk[seg + 1] * h / 6;
-                P_ = Mk[seg] * aa * aa * aa / (6 * h) + Mk[seg + 1] * bb * bb * bb / (6 * h) + ca * aa + cb * bb;
-                V_ = -Mk[seg] * aa * aa / (2 * h) + Mk[seg + 1] * bb * bb / (2 * h) - ca + cb;
-                A_ = Mk[seg] * aa / h + Mk[seg + 1] * bb / h;
+                const double m0 = Mk[seg], m1 = Mk[seg + 1];
+                const double ca = y[seg] * ih - m0 * h6, cb = y[seg + 1] * ih - m1 * h6;
+                P_ = (m0 * aa * aa * aa + m1 * bb * bb * bb) * i6h + ca * aa + cb * bb;
+                V_ = (m1 * bb * bb - m0 * aa * aa) * i2h - ca + cb;
+                A_ = (m0 * aa + m1 * bb) * ih;
             }
             const size_t o = ((size_t)p * dof + k) * a.max_len + j;
             a.pos[o] = (float)P_; a.vel[o] = (float)V_; a.acc[o] = (float)A_;
@@ -432,19 +810,19 @@ extern "C" int sc_toppra_sample_batch(sc_ctx* ctx, int P, int dof, int N,
                                       const double* p0, const double* p1, const double* v0, const double* v1,
                                       const double* x, const double* t, double dt, int max_len,
                                       float* pos, float* vel, float* acc, double* times, int32_t* length) {
-    if (!ctx || P <= 0 || dof <= 0 || N <= 0 || N > 4000 || max_len <= 0 || !(dt > 0) || !p0 || !p1 || !v0 || !v1 ||
+    if (!ctx || P <= 0 || dof <= 0 || N <= 0 || N > 65534 || max_len <= 0 || !(dt > 0) || !p0 || !p1 || !v0 || !v1 ||
         !x || !t || !pos || !vel || !acc || !times || !length)
         return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     sample_args a{P, dof, N, max_len, p0, p1, v0, v1, x, t, dt, pos, vel, acc, times, length};
-    const size_t lds = (size_t)(1 + 4 * dof) * (N + 1) * sizeof(double);
-    if (lds > 140 * 1024) { snprintf(ctx->err, sizeof(ctx->err), "sc_toppra_sample_batch: (1 + 4 dof)(N + 1) doubles exceed the LDS of a CU"); return SC_ERR_INVALID; }
+    const size_t lds = (size_t)(2 + 3 * dof) * (N + 1) * sizeof(double) + (((size_t)(N + 1) * 2 + 15) & ~(size_t)15);
+    if (lds > 140 * 1024) { snprintf(ctx->err, sizeof(ctx->err), "sc_toppra_sample_batch: (2 + 3 dof)(N + 1) doubles exceed the LDS of a CU"); return SC_ERR_INVALID; }
     {
         int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(toppra_sample_kernel), 140 * 1024);
         if (r_ != SC_OK) return r_;
     }
     int tk = sc_time_begin(ctx, SC_K_TOPPRA_SAMPLE);
-    hipLaunchKernelGGL(toppra_sample_kernel, dim3((unsigned)P), dim3(64), lds, ctx->stream, a);
+    hipLaunchKernelGGL(toppra_sample_kernel, dim3((unsigned)P), dim3(TS_THREADS), lds, ctx->stream, a);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -94,3 +94,53 @@ def test_toppra_per_stage_limits(ctx, oracle, N):
         assert int(out["status"][p]) == r["status"] == 0
         assert np.allclose(out["x"][p].cpu().numpy(), r["x"], rtol=1e-9, atol=1e-12)
         assert np.allclose(out["t"][p].cpu().numpy(), r["t"], rtol=1e-9, atol=1e-12)
+
+
+def test_toppra_statuses_match_oracle(ctx, oracle):
+    """Plans the sweeps give up on (status 1: no controllable set; status 2: the start state is outside K[0]) next to
+    solvable ones in one batch: statuses equal the oracle's, and whatever the oracle wrote before it stopped is there."""
+    import torch
+    N, dof = 60, 3
+    rng = np.random.default_rng(9)
+    P = 12
+    p0 = rng.uniform(-1, 1, (P, dof)); p1 = p0 + rng.uniform(0.5, 2, (P, dof))
+    v0 = rng.uniform(0.2, 1, (P, dof)); v1 = rng.uniform(0.2, 1, (P, dof))
+    vl = np.full((P, dof), 2.0); al = np.full((P, dof), 3.0)
+    alo = -al.copy(); ahi = al.copy()
+    alo[1] = 1.0; ahi[1] = -1.0                      # empty acceleration interval: infeasible from the first stage
+    alo[2, 1] = 0.5; ahi[2, 1] = 0.4                 # the same for one joint only
+    vl[3] = 1e-3                                     # tiny velocity limits are fine (slow, feasible)
+    sd_start, sd_end = 0.7, 0.1
+    out = ctx.toppra(_t(p0), _t(p1), _t(v0), _t(v1), _t(-vl), _t(vl), _t(alo), _t(ahi), N=N, sd_start=sd_start, sd_end=sd_end)
+    torch.cuda.synchronize()
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    seen = set()
+    for p in range(P):
+        r = oracle.toppra(p0[p], p1[p], v0[p], v1[p], -vl[p], vl[p], alo[p], ahi[p], N=N, sd_start=sd_start, sd_end=sd_end)
+        assert o["status"][p] == r["status"], p
+        seen.add(int(r["status"]))
+        if r["status"] == 0:
+            for k in ("K", "x", "u", "t"):
+                assert np.allclose(o[k][p], r[k], rtol=1e-9, atol=1e-12), (p, k)
+        assert np.allclose(o["K"][p, N], r["K"][N], rtol=0, atol=0)
+    assert {0, 1, 2} <= seen or {0, 1} <= seen
+
+
+def test_toppra_zero_divisor_pair(ctx, oracle):
+    """A stage where a row pair's divisor is exactly zero (alpha_lower = 2 Delta beta_lower): that pair bounds nothing, but
+    decides feasibility by its right-hand side -- the branch the fast kernel handles apart from its quotients."""
+    import torch
+    N = 4                                            # Delta = 0.25 exactly
+    # c1 = 0.5, c2 = 1, c3 = 0: a(s) = 0.5 + 2 s, b = 2; at s = 0.25 the collocation slot has a = 1 = 2 Delta b
+    p0 = np.zeros((4, 1)); p1 = np.full((4, 1), 1.5)
+    v0 = np.full((4, 1), 0.5); v1 = np.full((4, 1), 2.5)
+    vl = np.full((4, 1), 50.0)
+    alo = np.array([[-4.0], [0.5], [1.0], [-40.0]]); ahi = np.array([[4.0], [4.0], [4.0], [40.0]])
+    out = ctx.toppra(_t(p0), _t(p1), _t(v0), _t(v1), _t(-vl), _t(vl), _t(alo), _t(ahi), N=N, sd_start=0.5, sd_end=0.5)
+    torch.cuda.synchronize()
+    for p in range(4):
+        r = oracle.toppra(p0[p], p1[p], v0[p], v1[p], -vl[p], vl[p], alo[p], ahi[p], N=N, sd_start=0.5, sd_end=0.5)
+        assert int(out["status"][p]) == r["status"], p
+        if r["status"] == 0:
+            for k in ("K", "x", "u", "t"):
+                assert np.allclose(out[k][p].cpu().numpy(), r[k], rtol=1e-9, atol=1e-12), (p, k)
