@@ -53,6 +53,9 @@
 #define E_RUN (1u << 18)       // entry flag: the node's continuation in its arrival direction is already queued
 #define E_START (4u << 13 | 3u << 16)   // the start node: no parent (a diagonal arrival never has side flags)
 #define RUNK 8                 // cells of a same-f straight or diagonal run queued at once
+#ifndef WIDE_RUNS
+#define WIDE_RUNS 0            // runs in wide steps too (measured: fewer steps, but 1.6x the entries popped; slower on all maps but blocks)
+#endif
 
 struct astar_args {
     const uint8_t* moves;
@@ -199,6 +202,26 @@ __device__ __forceinline__ void pop_run_issue(const uint8_t* const (&ra)[RUNK - 
 __device__ __forceinline__ void pop_run_wait_loads(uint32_t (&rm)[RUNK - 1], uint32_t& pmv, uint32_t& old) {
     asm volatile("s_waitcnt vmcnt(1)" : "+v"(pmv), "+v"(old), "+v"(rm[0]), "+v"(rm[1]), "+v"(rm[2]), "+v"(rm[3]), "+v"(rm[4]), "+v"(rm[5]), "+v"(rm[6]) : : "memory");
 }
+// The legal-move bytes of the next RUNK - 1 cells of a wide step's successor lanes (issued behind the step's pair).
+__device__ __forceinline__ void run_loads_issue(const uint8_t* const (&ra)[RUNK - 1], uint32_t (&rm)[RUNK - 1]) {
+    asm volatile("global_load_ubyte %[r0], %[p0], off\n\t"
+                 "global_load_ubyte %[r1], %[p1], off\n\t"
+                 "global_load_ubyte %[r2], %[p2], off\n\t"
+                 "global_load_ubyte %[r3], %[p3], off\n\t"
+                 "global_load_ubyte %[r4], %[p4], off\n\t"
+                 "global_load_ubyte %[r5], %[p5], off\n\t"
+                 "global_load_ubyte %[r6], %[p6], off"
+                 : [r0] "=&v"(rm[0]), [r1] "=&v"(rm[1]), [r2] "=&v"(rm[2]), [r3] "=&v"(rm[3]), [r4] "=&v"(rm[4]), [r5] "=&v"(rm[5]), [r6] "=&v"(rm[6])
+                 : [p0] "v"(ra[0]), [p1] "v"(ra[1]), [p2] "v"(ra[2]), [p3] "v"(ra[3]), [p4] "v"(ra[4]), [p5] "v"(ra[5]), [p6] "v"(ra[6])
+                 : "memory");
+}
+__device__ __forceinline__ void run_loads_wait(uint32_t (&rm)[RUNK - 1]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rm[0]), "+v"(rm[1]), "+v"(rm[2]), "+v"(rm[3]), "+v"(rm[4]), "+v"(rm[5]), "+v"(rm[6]) : : "memory");
+}
+// wait for the atomic issued in front of RUNK - 1 run loads (memory operations return in order)
+__device__ __forceinline__ void atomic_wait_but(uint32_t& old, uint32_t (&rm)[RUNK - 1]) {
+    asm volatile("s_waitcnt vmcnt(7)" : "+v"(old), "+v"(rm[0]), "+v"(rm[1]), "+v"(rm[2]), "+v"(rm[3]), "+v"(rm[4]), "+v"(rm[5]), "+v"(rm[6]) : : "memory");
+}
 __device__ __forceinline__ void pop_pair_wait_load(uint32_t& pmv, uint32_t& old) { asm volatile("s_waitcnt vmcnt(1)" : "+v"(pmv), "+v"(old) : : "memory"); }
 
 // value of lane 8k (the only non-zero one of its group) in all 8 lanes of the group
@@ -212,6 +235,11 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 #define MARK(i, v) do { if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(&a.counter[8 + (i)], (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 #else
 #define MARK(i, v) do { } while (0)
+#endif
+#ifdef ASTAR_STAMPS    // measurement aid: cycles per phase of the wide steps, left in the first words of the query's path
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp[i] += (long long)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
 #endif
 
 // One query, by one wavefront, in scratch slot `slot`.
@@ -266,6 +294,11 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 
     bool found = false, ovf = false;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#ifdef ASTAR_STAMPS
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = t_begin;
+    int nwide = 0, nrounds = 0;
+#endif
     // Every step pops at least one entry and a search pushes at most 8 entries per cell: a bound that a correct
     // search cannot reach, so that no wavefront can spin forever whatever the state of its scratch memory.
     int steps_left = (int)(8 * cells + 1024 < 0x7FFFFFFF ? 8 * cells + 1024 : 0x7FFFFFFF);
@@ -301,13 +334,6 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         }
         lt = __builtin_amdgcn_readfirstlane(lt);   // wave-uniform by construction; says so to the compiler
     };
-    // Push the successor reached by move d from (x, y) (whose full legal-move byte is pmv) -- `act` lanes only.
-    auto push = [&](const bool act, const int x, const int y, const int d, const uint32_t pmv, const int hc) {
-        const int ddx_ = (int)((0x2252u >> (2 * d)) & 3u) - 1, ddy_ = (int)((0x0A25u >> (2 * d)) & 3u) - 1;
-        const int nx = x + ddx_, ny = y + ddy_;
-        push_entry(act, entry_pack(nx, ny, d, pmv), (d < 4 ? 10 : 14) + octile(nx, ny, gx, gy) - hc);
-    };
-
     for (;;) {
         const int b = fcur & 31;
         const uint32_t* bq = bk + (size_t)b * cap;
@@ -377,6 +403,11 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 if (won && d == 0) g[gix(x, y, tw)] = (uint32_t)(fcur - hc);
             } else {
                 // ---- wide step: one lane per node, then the legal successors of all nodes 64 at a time ----
+                // The successor list is built while the atomic is still under way, as if every node were won (most are);
+                // the successors of a node that turns out to be somebody else's are dropped when they would be pushed.
+                // Same-f successors look RUNK cells ahead exactly as in the narrow step (their loads go out before the
+                // atomic is waited for), so the equal-f chains of a wide frontier advance RUNK cells per step too.
+                STAMP(0);   // everything outside the wide steps
                 const bool valid = lane < n;
                 const uint32_t e = valid ? qe[(lh + lane) & (CQ - 1)] : 0u;
                 lh += n;
@@ -386,13 +417,10 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 pop_pair_issue(mvs + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
                 const uint32_t prune = entry_prune(e);
                 const int hc = octile(x, y, gx, gy);
+                STAMP(1);   // pop and issue
                 pop_pair_wait_load(pmv, old);
-                atomic_wait(old);
-                const bool won = valid && !(old & bit);   // duplicates inside one pop: the atomics serialise, one lane wins
-                nexp += __popcll(__ballot(won));
-                if (__ballot(won && x == gx && y == gy)) found = true;
-                if (won) g[gix(x, y, tw)] = (uint32_t)(fcur - hc);
-                uint32_t mv = won ? (pmv & ~prune) : 0u;
+                STAMP(2);   // the load
+                uint32_t mv = valid ? (pmv & ~prune) : 0u;
                 nd_xy[lane] = (uint32_t)y << 16 | (uint32_t)x;
                 nd_mv[lane] = pmv;
                 // exclusive prefix of the successor counts (<= 8 each) from four ballots
@@ -410,13 +438,69 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     succ[base++] = (uint16_t)(lane << 3 | dd);
                 }
                 wave_lds_sync();
+                STAMP(3);   // successor list
+                bool won = false;
+#ifdef ASTAR_STAMPS
+                ++nwide;
+#endif
                 for (int j0 = 0; j0 < total; j0 += 64) {
+#ifdef ASTAR_STAMPS
+                    ++nrounds;
+#endif
                     const bool act = j0 + lane < total;
                     const uint32_t sd = act ? succ[j0 + lane] : 0u;
-                    const uint32_t xy = nd_xy[sd >> 3];
+                    const int par = (int)(sd >> 3), d = (int)(sd & 7u);
+                    const uint32_t xy = nd_xy[par], pmvp = nd_mv[par];
                     const int px = xy & 0xFFFF, py = xy >> 16;
-                    push(act, px, py, (int)(sd & 7u), nd_mv[sd >> 3], octile(px, py, gx, gy));
+                    const int ddx_ = (int)((0x2252u >> (2 * d)) & 3u) - 1, ddy_ = (int)((0x0A25u >> (2 * d)) & 3u) - 1;
+                    const int nx = px + ddx_, ny = py + ddy_;
+                    const int df = (d < 4 ? 10 : 14) + octile(nx, ny, gx, gy) - octile(px, py, gx, gy);
+                    const int adx = abs(gx - px), ady = abs(gy - py);
+                    const int lgeom = d >= 4 ? min(adx, ady) : abs(adx - ady);
+                    const int lmax = WIDE_RUNS && act && df == 0 ? min(RUNK, lgeom) : 1;
+                    const int so = ddy_ * W + ddx_;
+                    const uint8_t* const cell = mvs + (py * W + px);
+                    const uint8_t* ra[RUNK - 1];
+                    uint32_t rm[RUNK - 1];
+#pragma unroll
+                    for (int k = 1; k < RUNK; ++k) ra[k - 1] = cell + min(k, lmax - 1) * so;
+                    if (WIDE_RUNS) run_loads_issue(ra, rm);
+                    if (j0 == 0) {
+                        // the pop's atomic is older than the run loads: in-order return, RUNK - 1 operations may remain
+                        STAMP(4);   // first round's preparation
+                        if (WIDE_RUNS) atomic_wait_but(old, rm); else atomic_wait(old);
+                        STAMP(5);   // the atomic
+                        won = valid && !(old & bit);   // duplicates inside one pop: the atomics serialise, one lane wins
+                        nexp += __popcll(__ballot(won));
+                        if (__ballot(won && x == gx && y == gy)) found = true;
+                        nd_mv[lane] = pmv | (won ? 0x100u : 0u);
+                        wave_lds_sync();
+                    }
+                    const bool go = act && ((nd_mv[par] >> 8) & 1u);
+                    int run = 1;
+                    if (WIDE_RUNS) {
+                        run_loads_wait(rm);
+#pragma unroll
+                        for (int k = 1; k < RUNK; ++k)
+                            if (run == k && k < lmax && ((rm[k - 1] >> d) & 1u)) run = k + 1;
+                    }
+                    push_entry(go, entry_pack(nx, ny, d, pmvp) | (run > 1 ? E_RUN : 0u), df);
+                    if (WIDE_RUNS) {
+#pragma unroll
+                        for (int k = 2; k <= RUNK; ++k) {
+                            if (__ballot(go && run >= k) == 0) break;
+                            push_entry(go && run >= k, entry_pack(px + k * ddx_, py + k * ddy_, d, rm[k - 2]) | (run > k ? E_RUN : 0u), 0);
+                        }
+                    }
                 }
+                if (total == 0) {
+                    atomic_wait(old);
+                    won = valid && !(old & bit);
+                    nexp += __popcll(__ballot(won));
+                    if (__ballot(won && x == gx && y == gy)) found = true;
+                }
+                if (won) g[gix(x, y, tw)] = (uint32_t)(fcur - hc);
+                STAMP(6);   // pushes
             }
             // wave-uniform by construction (ballots, popcounts); the joins above hide that from the compiler, which would
             // otherwise run these loops under EXEC masks with the counters in VGPRs
@@ -500,6 +584,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         }
     }
     kcyc = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+#ifdef ASTAR_STAMPS
+    if (lane == 0 && a.Lmax >= 16) {
+        for (int i = 0; i < 8; ++i) path[i] = (int)(stamp[i] >> 10);
+        path[8] = nwide; path[9] = nrounds;
+    }
+#endif
     }   // search
     if (lane == 0) {
         a.status[q] = out_st; a.len[q] = out_len; a.cost[q] = out_cost;
