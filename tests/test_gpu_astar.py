@@ -152,3 +152,32 @@ def test_astar_multi_grid_launch(ctx, oracle):
         sel = np.flatnonzero(qgrid == k)
         ref = oracle.astar_batch(d2, s[sel], g[sel], Lmax=2048, nthreads=4)
         _compare({kk: vv[sel] for kk, vv in got.items()}, ref, sel.shape[0])
+
+
+def test_astar_ring_overflow_retry(ctx, oracle, monkeypatch):
+    """Bucket rings far too small for the map (SC_ASTAR_CAP = 1024 entries per level): the first launch gives up on the
+    wide searches, the device-side retry launch (16x the ring space, enqueued behind it without a host round trip)
+    finishes them.  Every query that reports SC_Q_OK must equal the oracle; what even the retry cannot hold is reported
+    as SC_Q_RING_OVERFLOW, never as a wrong path."""
+    import ctypes as C
+    import torch
+    import sea_current_amd as sc
+    from sea_current_amd import synth
+    occ = synth.salt_grid(768, 768, 0.05, seed=5)
+    d2 = oracle.edt(occ)
+    s, g = synth.queries(d2 >= 1, 96, seed=6)
+    ref = oracle.astar_batch(d2, s, g, Lmax=4096, nthreads=8)
+    monkeypatch.setenv("SC_ASTAR_CAP", "1024")
+    got = _run(ctx, d2, s, g, Lmax=4096)
+    buf = (C.c_int32 * 16)()
+    ctx._l.sc_astar_debug_peek(ctx._h, buf)
+    assert buf[1] > 0, "the small rings were expected to overflow in the first launch"
+    ok = got["status"] == 0
+    assert ok.sum() > 0 and set(np.unique(got["status"])) <= {0, sc.Q_RING_OVERFLOW}
+    assert (ok.sum() > (96 - buf[1])), "the retry launch finished none of the overflowed queries"
+    assert np.array_equal(got["cost"][ok], ref["cost"][ok]) and np.array_equal(got["len"][ok], ref["len"][ok])
+    for q in np.flatnonzero(ok):
+        assert np.array_equal(got["path"][q, :ref["len"][q]], ref["path"][q, :ref["len"][q]]), q
+    # with the default rings everything is found, first launch
+    monkeypatch.delenv("SC_ASTAR_CAP")
+    _compare(_run(ctx, d2, s, g, Lmax=4096), ref, 96)
