@@ -433,6 +433,30 @@ def main():
                           "q8192 = the whole 8k-query frame on ONE GPU, q1024 = one GPU's share when 8 GPUs split the frame")
         result["replan_stream"] = replan
 
+    # ---- BASELINE configs[3], one GPU's share: 4096^2 grid, 8192 of the 64k queries (rank 0's block), N = 1 only ----
+    if rank == 0 and world == 1 and not args.only_main_map:
+        W4 = H4 = 4096
+        occ4 = torch.from_numpy(make_grid(args.map, W4, H4)).to(dev)
+        d4 = ctx.edt(occ4)
+        torch.cuda.synchronize()
+        Q4 = 8192
+        s4, g4 = synth.queries(d4.cpu().numpy() >= 1, Q4)            # queries 0 .. 8191 of the 64k (rank 0 of 8)
+        s4d, g4d = torch.from_numpy(s4).to(dev), torch.from_numpy(g4).to(dev)
+        L4 = 4 * args.lmax
+        o4 = ctx.astar_batch(ctx.edt(occ4), s4d, g4d, Lmax=L4)       # warm-up (scratch allocation)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o4 = ctx.astar_batch(ctx.edt(occ4), s4d, g4d, Lmax=L4)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t0
+        ex4 = ctx.astar_last_expansions()
+        st4 = o4["status"].cpu().numpy()
+        result["config3_one_gpu_share"] = {"workload": f"{W4}x{H4} {args.map} grid, EDT + A*, {Q4} queries (one GPU's block of the 64k), Lmax {L4}",
+                                           "ms": dt4 * 1e3, "plans_per_s": Q4 / dt4, "expansions": int(ex4), "G_expansions_per_s": ex4 / dt4 / 1e9,
+                                           "found": int((st4 == 0).sum()), "truncated": int((st4 == 3).sum()), "ring_overflow": int((st4 == 4).sum()),
+                                           "note": "the 8-GPU job gathers 8 such blocks with sc_allgather_paths; not measured on more than one GPU"}
+        del occ4, d4, o4
+
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only, never the measured product

@@ -73,7 +73,7 @@ struct astar_args {
     int32_t* len;
     int32_t* cost;
     int32_t* status;
-    uint32_t* g;         // [slots][gcells], 4 x 4-cell tiles; valid where the closed bit is set
+    void* g;             // [slots][gcells] of GT (astar_kernel<GT>): valid where the closed bit is set
     uint32_t* closed;    // [slots][bwords], 32 x 16-cell tiles
     uint32_t* buckets;   // [slots][NBUCKET][cap]
     int cap;             // power of two
@@ -97,12 +97,23 @@ __device__ __forceinline__ int octile(int x, int y, int gx, int gy) {
 __device__ __forceinline__ uint32_t gix(int x, int y, int tw) {
     return ((((uint32_t)(y >> 2) * (uint32_t)tw + (uint32_t)(x >> 2)) << 4) | ((uint32_t)(y & 3) << 2)) | (uint32_t)(x & 3);
 }
+// The batch kernel keeps g modulo 256, one byte per cell in tiles of 8 x 8 cells (one 64-byte line): the only reader is
+// the parent-chain extraction, which asks whether g[n] + w == g[c] for a CLOSED neighbour n of c, and closed neighbours
+// joined by a legal move differ by at most 14 in g (the move is legal both ways), so equality modulo 256 is equality.
+// A quarter of the scratch and of the L2 footprint of full words; sc_astar_gfield runs the kernel with full words.
+__device__ __forceinline__ uint32_t gix8(int x, int y, int tw8) {
+    return ((((uint32_t)(y >> 3) * (uint32_t)tw8 + (uint32_t)(x >> 3)) << 6) | ((uint32_t)(y & 7) << 3)) | (uint32_t)(x & 7);
+}
+template <typename GT> __device__ __forceinline__ uint32_t gidx(int x, int y, int tw);
+template <> __device__ __forceinline__ uint32_t gidx<uint32_t>(int x, int y, int tw) { return gix(x, y, tw); }
+template <> __device__ __forceinline__ uint32_t gidx<uint8_t>(int x, int y, int tw) { return gix8(x, y, tw); }
 // word of cell (x, y) in the closed bitmap (bit x & 31): tiles of 32 x 16 cells = one 64-byte line
 __device__ __forceinline__ uint32_t cix(int x, int y, int bw) {
     return (((uint32_t)(y >> 4) * (uint32_t)bw + (uint32_t)(x >> 5)) << 4) | (uint32_t)(y & 15);
 }
 
-__device__ __forceinline__ uint32_t g_load(const uint32_t* p) {
+template <typename T>
+__device__ __forceinline__ T g_load(const T* p) {
     // agent-scope relaxed load: served by L2, where this wave's stores have landed
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -243,6 +254,7 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 #endif
 
 // One query, by one wavefront, in scratch slot `slot`.
+template <typename GT>
 __device__ __forceinline__ void astar_query(const astar_args& a, const int q, const int slot) {
     __shared__ uint32_t qe[CQ];            // LDS ring of the current f level
     __shared__ int s_head[NBUCKET];        // head / tail of the 32 HBM rings: lanes that insert take their slot with one
@@ -269,7 +281,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     } else {
     MARK(0, 1);
     const int tw = a.tw, bw = a.bw;
-    uint32_t* g = a.g + (size_t)slot * a.gcells;
+    GT* g = static_cast<GT*>(a.g) + (size_t)slot * a.gcells;
     uint32_t* cl = a.closed + (size_t)slot * a.bwords;
     uint32_t* bk = a.buckets + (size_t)slot * NBUCKET * a.cap;
     const int cap = a.cap, capm = a.cap - 1;
@@ -400,7 +412,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 }
                 nexp += __popcll(__ballot(won && d == 0));
                 if (__ballot(won && x == gx && y == gy)) found = true;
-                if (won && d == 0) g[gix(x, y, tw)] = (uint32_t)(fcur - hc);
+                if (won && d == 0) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
             } else {
                 // ---- wide step: one lane per node, then the legal successors of all nodes 64 at a time ----
                 // The successor list is built while the atomic is still under way, as if every node were won (most are);
@@ -499,7 +511,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     nexp += __popcll(__ballot(won));
                     if (__ballot(won && x == gx && y == gy)) found = true;
                 }
-                if (won) g[gix(x, y, tw)] = (uint32_t)(fcur - hc);
+                if (won) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
                 STAMP(6);   // pushes
             }
             // wave-uniform by construction (ballots, popcounts); the joins above hide that from the compiler, which would
@@ -551,8 +563,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     const int n = ny * W + nx;
                     if ((mvs[n] >> d) & 1) {
                         const uint32_t cw = g_load(&cl[cix(nx, ny, bw)]);
-                        const uint32_t gn = g_load(&g[gix(nx, ny, tw)]);
-                        ok = ((cw >> (nx & 31)) & 1u) && gn == gc - (d < 4 ? 10u : 14u);  // closed in this search and g[n] + w == g[c]
+                        const GT gn = g_load(&g[gidx<GT>(nx, ny, tw)]);
+                        ok = ((cw >> (nx & 31)) & 1u) && gn == (GT)(gc - (d < 4 ? 10u : 14u));  // closed in this search and g[n] + w == g[c]
                     }
                 }
             }
@@ -597,6 +609,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     }
 }
 
+template <typename GT>
 __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
     const int nq = a.nq_dev ? *a.nq_dev : a.nq;
     for (;;) {
@@ -604,7 +617,7 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         // queue loop); the queue position is the counter in units of a wavefront
         const int qi = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, 1)) >> 6;
         if (qi >= nq) break;
-        astar_query(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+        astar_query<GT>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
     }
 }
 
@@ -658,7 +671,7 @@ static int astar_resident_waves(sc_ctx* ctx) {
     if (ctx->astar_waves > 0) return ctx->astar_waves;
     int per_cu = 0, dev = ctx->device;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel<uint8_t>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) prop.multiProcessorCount = 256;
     int w = per_cu * prop.multiProcessorCount;
     if (const char* e = getenv("SC_ASTAR_WAVES")) { const int v = atoi(e); if (v > 0) w = v; }
@@ -668,10 +681,12 @@ static int astar_resident_waves(sc_ctx* ctx) {
 
 static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid, int W, int H, int32_t r2, const int32_t* start,
                      const int32_t* goal, int Q, int Lmax, int32_t* path, int32_t* len, int32_t* cost,
-                     int32_t* status) {
+                     int32_t* status, bool full_g = false) {
     const size_t cells = (size_t)W * H;
-    const int tw = (W + 3) >> 2, bw = (W + 31) >> 5;
-    const size_t gcells = (size_t)tw * ((H + 3) >> 2) * 16;   // g array: whole 4 x 4 tiles
+    const int tw = full_g ? (W + 3) >> 2 : (W + 7) >> 3, bw = (W + 31) >> 5;
+    // g array: whole 4 x 4 tiles of words (sc_astar_gfield), whole 8 x 8 tiles of bytes otherwise
+    const size_t gcells = full_g ? (size_t)tw * ((H + 3) >> 2) * 16 : (size_t)tw * ((H + 7) >> 3) * 64;
+    const size_t gsz = full_g ? 4 : 1;
     const size_t bwords = (size_t)bw * ((H + 15) >> 4) * 16;  // closed bitmap: whole 32 x 16 tiles
     const int32_t rmin = r2 > 1 ? r2 : 1;
     int r = sc_scratch_reserve(ctx, &ctx->moves, cells * (size_t)G);
@@ -694,13 +709,13 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
         while (want < 64 * (W > H ? W : H)) want <<= 1;
         if (cap < want) cap = want;
     }
-    const size_t per_slot = gcells * 4 + bwords * 4 + (size_t)NBUCKET * cap * 4;
+    const size_t per_slot = gcells * gsz + bwords * 4 + (size_t)NBUCKET * cap * 4;
     size_t slots = ctx->astar_slot_budget / per_slot;
     const size_t resident = (size_t)astar_resident_waves(ctx);
     if (slots > resident) slots = resident;
     if (slots > (size_t)Q) slots = Q;
     if (slots < 1) slots = 1;
-    r = sc_scratch_reserve(ctx, &ctx->gslots, slots * gcells * 4);
+    r = sc_scratch_reserve(ctx, &ctx->gslots, slots * gcells * gsz);
     if (r != SC_OK) return r;
     r = sc_scratch_reserve(ctx, &ctx->closed, slots * bwords * 4);
     if (r != SC_OK) return r;
@@ -718,9 +733,10 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     int tk = sc_time_begin(ctx, SC_K_ASTAR);
     hipLaunchKernelGGL(astar_prep_kernel, dim3(1), dim3(1024), 0, ctx->stream, start, goal, Q, W, H, sorted ? order : (int32_t*)nullptr, ctr);
     astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, qgrid, sorted ? order : nullptr, nullptr, Q, Lmax, path, len,
-                 cost, status, (uint32_t*)ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
+                 cost, status, ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
                  ovf_list, ctr + 1, ctr + 4, Q, tw, bw, gcells, bwords};
-    hipLaunchKernelGGL(astar_kernel, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
+    if (full_g) hipLaunchKernelGGL(astar_kernel<uint32_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(astar_kernel<uint8_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
     // retry pass over the overflow list (normally empty: the wavefronts read the count and leave)
     {
         const size_t rslots = slots >= 16 ? slots / 16 : 1;
@@ -728,7 +744,8 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
         astar_args b = a;
         b.order = ovf_list; b.nq_dev = ctr + 1; b.nq = 0; b.cap = rcap; b.counter = ctr + 2;
         b.ovf_list = order; b.ovf_count = ctr + 3;   // a second overflow stays in status (SC_Q_RING_OVERFLOW); the list is scratch
-        hipLaunchKernelGGL(astar_kernel, dim3((unsigned)rslots), dim3(64), 0, ctx->stream, b);
+        if (full_g) hipLaunchKernelGGL(astar_kernel<uint32_t>, dim3((unsigned)rslots), dim3(64), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(astar_kernel<uint8_t>, dim3((unsigned)rslots), dim3(64), 0, ctx->stream, b);
     }
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
@@ -784,7 +801,7 @@ extern "C" int sc_astar_gfield(sc_ctx* ctx, const int32_t* d2, int W, int H, int
     SC_HIP(ctx, hipMemcpyAsync(sg, h, 8, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // Lmax = 1: the path is not wanted; a found path reports SC_Q_TRUNCATED
-    r = astar_run(ctx, d2, 1, nullptr, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status);
+    r = astar_run(ctx, d2, 1, nullptr, W, H, r2_clear, sg, sg + 1, 1, 1, sg + 4, sg + 2, cost, status, /*full_g=*/true);
     if (r != SC_OK) return r;
     // one query: it ran in slot 0 of the main pass, or of the retry pass (same slot 0)
     hipLaunchKernelGGL(gfield_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -1,5 +1,6 @@
 // ctx.hip -- context, stream, scratch, launch timing and the `_host` convenience wrappers.
 #include "sc_internal.h"
+#include <stdlib.h>
 
 extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
 
@@ -28,6 +29,8 @@ extern "C" int sc_ctx_create(int device, sc_ctx** out) {
         return SC_ERR_HIP;
     }
     c->stream = c->own_stream;
+    // scratch the A* slots of this context may take, in GiB (a slot = one resident wavefront's g array, closed bitmap and rings)
+    if (const char* e = getenv("SC_ASTAR_SLOT_GB")) { const long v = atol(e); if (v >= 1 && v <= 256) c->astar_slot_budget = (size_t)v << 30; }
     *out = c;
     return SC_OK;
 }

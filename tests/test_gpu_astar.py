@@ -181,3 +181,22 @@ def test_astar_ring_overflow_retry(ctx, oracle, monkeypatch):
     # with the default rings everything is found, first launch
     monkeypatch.delenv("SC_ASTAR_CAP")
     _compare(_run(ctx, d2, s, g, Lmax=4096), ref, 96)
+
+
+def test_astar_full_headline_batch(ctx, oracle):
+    """The whole headline batch (BASELINE configs[1]: 1024 queries on the 1024^2 salt20 grid, the bench's own inputs), every
+    query against the oracle: status, cost, length, path, and the number of expanded nodes."""
+    import torch
+    from sea_current_amd import synth
+    occ = synth.salt_grid(1024, 1024, 0.20)
+    d2 = ctx.edt(torch.from_numpy(occ).cuda())
+    torch.cuda.synchronize()
+    d2h = d2.cpu().numpy()
+    assert np.array_equal(d2h, oracle.edt(occ))
+    s, g = synth.queries(d2h >= 1, 1024)
+    out = ctx.astar_batch(d2, torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), Lmax=4096)
+    torch.cuda.synchronize()
+    ex = ctx.astar_debug_stats(1024)[0]
+    ref = oracle.astar_batch(d2h, s, g, Lmax=4096, nthreads=16)
+    _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 1024)
+    assert np.array_equal(ex, ref["expanded"])
