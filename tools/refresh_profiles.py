@@ -85,15 +85,17 @@ print("A*:", json.dumps({k: v for k, v in astar.items() if k not in ("counters_p
 # ---- TOPP-RA instruction counts ----
 tp = {}
 path = os.path.join(src, "toppra_pmc", "t_counter_collection.csv")
-for kern in ("toppra_kernel", "toppra_sample_kernel"):
+for kern in ("toppra_fast_kernel", "toppra_sample_kernel"):
     tp[kern] = {}
     for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES"):
-        v = per_dispatch(path, n, kern + "<" if kern == "toppra_kernel" else kern)
+        v = per_dispatch(path, n, kern)
         tp[kern][n + "_per_launch"] = sum(v) / len(v)
     tp[kern]["per_plan"] = {n: tp[kern][n + "_per_launch"] / 1024 for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU")}
     tp[kern]["wave_cycles_x4_per_plan"] = 4 * tp[kern]["SQ_WAVE_CYCLES_per_launch"] / 1024
-tp["workload"] = "1024 plans, 6 joints, 200 stages (tools/toppra_one.py); one wavefront per plan: per-plan = per-wave; a sweep is 400 dependent stages"
-tp["toppra_kernel"]["VALU_per_stage"] = tp["toppra_kernel"]["per_plan"]["SQ_INSTS_VALU"] / 400
+tp["workload"] = ("1024 plans, 6 joints, 200 stages (tools/toppra_one.py); sweep kernel: three wavefronts per plan (chains | pair elimination / "
+                  "forward coefficients | slots / backward coefficients), counts are sums over the three; a plan is 400 dependent stages")
+tp["toppra_fast_kernel"]["VALU_per_stage"] = tp["toppra_fast_kernel"]["per_plan"]["SQ_INSTS_VALU"] / 400
+tp["round2_first_version"] = {"VALU_per_stage": 226, "ms_sweep": 0.522, "ms_sample": 0.180, "note": "one wavefront per plan, exact divisions on the chains"}
 json.dump(tp, open(os.path.join(dst, f"{tag}_toppra_pmc.json"), "w"), indent=1)
 print("TOPP-RA:", json.dumps(tp, indent=1))
 for f in sorted(os.listdir(dst)):
