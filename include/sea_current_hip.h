@@ -134,7 +134,11 @@ int sc_moves_i32_u8(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_cle
  *   len, cost, status : int32 [Q]  (cost = -1, len = 0 when there is no path)
  * Takes over planning_space::fast_marching_trees (sea_current.hpp:1339-1407)
  * with its helpers near (:1328-1337) and sample_free (:1294-1313): same role
- * (start, goal) -> optional waypoint list, on a grid instead of Halton samples. */
+ * (start, goal) -> optional waypoint list, on a grid instead of Halton samples.
+ * Scratch: every search in flight owns W*H bytes of g, W*H/8 of closed bits and its open-list rings (9 MiB at 1024^2,
+ * 50 MiB at 4096^2); a context takes at most 96 GiB for them (environment SC_ASTAR_SLOT_GB when the context is created)
+ * and serves longer query lists from the same slots.  Only enqueues: a full ring is handled on the device (a second,
+ * normally empty, launch with 16x the ring space); what that cannot hold either reports SC_Q_RING_OVERFLOW. */
 int sc_astar_batch(sc_ctx* ctx, const int32_t* d2, int W, int H, int32_t r2_clear,
                    const int32_t* start, const int32_t* goal, int Q, int Lmax,
                    int32_t* path, int32_t* len, int32_t* cost, int32_t* status);

@@ -14,7 +14,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 NATIVE_DIR = os.path.normpath(os.path.join(_PKG, "..", ".."))          # sea-current_amd/
 REPO_ROOT = os.path.normpath(os.path.join(NATIVE_DIR, ".."))
-LIB_PATH = os.path.join(NATIVE_DIR, "libsea_current_hip.so")
+LIB_PATH = os.environ.get("SC_LIB_PATH") or os.path.join(NATIVE_DIR, "libsea_current_hip.so")   # SC_LIB_PATH: experiment builds
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "sea_current_hip.h")
 
 EDT_INF = 2**31 - 1
