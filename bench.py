@@ -398,7 +398,7 @@ def main():
         result["toppra"] = {"plans": P, "dof": dof, "stages": N, "ok": ok_plans, "ms_sweep": ms_t / 10, "ms_sample": ms_s / 10,
                             "plans_per_s": P / ((ms_t + ms_s) / 10 * 1e-3), "algorithmic_GBps": tbytes / (ms_t / 10 * 1e-3) / 1e9,
                             "hbm_frac": tbytes / (ms_t / 10 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "latency-bound (two dependent 200-stage sweeps per plan), not HBM-bound"}
+                            "note": "bound by instruction issue (two dependent 200-stage sweeps per plan and 4 dof^2 row pairs per stage), not by HBM"}
 
     # ---- dynamic-obstacle replan stream (BASELINE configs[4]), N = 1 only: reported, not part of `value` ----
     if rank == 0 and world == 1 and args.replan_frames > 0:
