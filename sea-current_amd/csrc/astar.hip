@@ -253,8 +253,19 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 #define STAMP(i) do { } while (0)
 #endif
 
-// One query, by one wavefront, in scratch slot `slot`.
-template <typename GT>
+// One query in scratch slot `slot`: by one wavefront (DUAL = false), or by two (DUAL = true, astar_kernel_dual: batches
+// small enough to give every query two resident wavefronts).  A search is bound by what ONE wavefront can issue per
+// frontier step, so the second wavefront takes the part of a wide step that the next step does not wait for:
+//   wavefront 0 pops, closes (the atomic OR), and queues only the SAME-f successors -- at most two moves per node are
+//     same-f (the diagonal towards the goal and the straight move along the major axis), known from the geometry without
+//     any list -- then hands every node it won to wavefront 1 through a ring in LDS and goes on to the next step;
+//   wavefront 1 stores g and pushes the successors of later levels (successor list, HBM rings), one batch of up to 64
+//     handed-over nodes at a time, whenever there are any.
+// They meet only when a level is exhausted: wavefront 0 waits until wavefront 1 has nothing left (everything for the
+// later levels is then in their rings) before it picks the next level.  No barrier per step -- the two earlier
+// multi-wavefront forms (tools/microbench/astar_*_experiment.hip.txt) lost exactly there.
+#define HQ 256   // records of the hand-over ring
+template <typename GT, bool DUAL>
 __device__ __forceinline__ void astar_query(const astar_args& a, const int q, const int slot) {
     __shared__ uint32_t qe[CQ];            // LDS ring of the current f level
     __shared__ int s_head[NBUCKET];        // head / tail of the 32 HBM rings: lanes that insert take their slot with one
@@ -262,7 +273,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint32_t nd_xy[64];         // wide steps: the popped nodes (y << 16 | x) and their legal-move bytes
     __shared__ uint32_t nd_mv[64];
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
-    const int lane = threadIdx.x;
+    __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
+    __shared__ uint32_t hq_xy[DUAL ? HQ : 1], hq_m[DUAL ? HQ : 1], hq_f[DUAL ? HQ : 1];   // hand-over ring: node, moves | legal moves << 8, f
+    __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf;
+    constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
+    const int lane = threadIdx.x & 63;
+    const int wv = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int W = a.W, H = a.H;
     const size_t cells = (size_t)W * H;
     const int s = a.start[q], t = a.goal[q];
@@ -276,7 +292,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     const bool bad = s < 0 || t < 0 || (size_t)s >= cells || (size_t)t >= cells || a.d2[grid_off + s] < a.rmin || a.d2[grid_off + t] < a.rmin;
     if (bad) out_st = SC_Q_BAD_ENDPOINT;
     else if (s == t) {
-        if (lane == 0) path[0] = s;
+        if (lane == 0 && wv == 0) path[0] = s;
         out_len = 1; out_cost = 0;
     } else {
     MARK(0, 1);
@@ -293,21 +309,26 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     {
         uint4* p = reinterpret_cast<uint4*>(cl);
         const size_t n4 = a.bwords >> 2;
-        for (size_t i = lane; i < n4; i += 64) p[i] = make_uint4(0, 0, 0, 0);
+        for (size_t i = DUAL ? threadIdx.x : lane; i < n4; i += DUAL ? 128 : 64) p[i] = make_uint4(0, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();   // the previous query's last LDS reads are done before the rings are reset
-    if (lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
+    if (wv == 0 && lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
+    if (wv == 0) prune_tbl[lane] = (uint8_t)entry_prune((uint32_t)lane << 13);
     int fcur = octile(sx, sy, gx, gy);
-    if (lane == 0) qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
+    if (wv == 0 && lane == 0) {
+        qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
+        hq_tail = 0; hq_head = 0; hq_clean = 0; hq_stop = 0; hq_ovf = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bitmap is clear before the first atomic OR
     wave_lds_sync();
+    if (DUAL) __syncthreads();
     int lh = 0, lt = 1;  // LDS ring of the current f (wave-uniform)
     MARK(0, 2);
 
     bool found = false, ovf = false;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #ifdef ASTAR_STAMPS
-    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = t_begin;
     int nwide = 0, nrounds = 0;
 #endif
@@ -340,12 +361,99 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         // other levels: one LDS atomic per inserting lane hands out its slot in the HBM ring
         if (act && (df != 0 || spill)) {
             const int bb = (fcur + df) & 31;
-            const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (pos - __hip_atomic_load(&s_head[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >= cap) ovf = true;
+            const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, SCOPE);
+            if (pos - __hip_atomic_load(&s_head[bb], __ATOMIC_RELAXED, SCOPE) >= cap) ovf = true;
             else bk[(size_t)bb * cap + (pos & capm)] = ne;
         }
         lt = __builtin_amdgcn_readfirstlane(lt);   // wave-uniform by construction; says so to the compiler
     };
+    int hq_tl = 0, hq_hd = 0;   // DUAL, wavefront 0: records handed over so far; wavefront 1's progress as last seen
+    // DUAL, wavefront 0: hand the nodes of the `rec` lanes (node (hx, hy), moves left to push hm, legal moves hp) to wavefront 1
+    auto hand_over = [&](const bool rec, const int hx, const int hy, const uint32_t hm, const uint32_t hp) {
+        const unsigned long long wm = __ballot(rec);
+        if (wm) {
+            const int cnt = __popcll(wm);
+            while (hq_tl + cnt - hq_hd > HQ) {     // wavefront 1 is a whole ring behind (as far as we know): look again
+                hq_hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_head, __ATOMIC_RELAXED, SCOPE));
+                if (hq_tl + cnt - hq_hd > HQ) __builtin_amdgcn_s_sleep(1);
+            }
+            if (rec) {
+                const int r = (hq_tl + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))) & (HQ - 1);
+                hq_xy[r] = (uint32_t)hy << 16 | (uint32_t)hx;
+                hq_m[r] = hm | hp << 8;
+                hq_f[r] = (uint32_t)fcur;
+            }
+            hq_tl += cnt;
+            wave_lds_sync();
+            if (lane == 0) __hip_atomic_store(&hq_tail, hq_tl, __ATOMIC_RELAXED, SCOPE);
+        }
+        return wm;
+    };
+    if (DUAL && wv == 1) {
+        // ---- wavefront 1: g and the later-level successors of the nodes wavefront 0 has won ----
+        int hd = 0;
+        bool dirty = false;
+        for (;;) {
+            const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_tail, __ATOMIC_RELAXED, SCOPE));
+            const int stop = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_stop, __ATOMIC_RELAXED, SCOPE));
+            wave_lds_sync();
+            if (tl == hd) {
+                if (dirty) {
+                    // nothing left: once the stores have landed, say so (wavefront 0 waits for this at the end of a level)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&hq_clean, hd, __ATOMIC_RELAXED, SCOPE);
+                    dirty = false;
+                }
+                if (stop) break;
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            const int n = min(tl - hd, 64);
+            const bool valid = lane < n;
+            const int r = (hd + lane) & (HQ - 1);
+            const uint32_t xy = valid ? hq_xy[r] : 0u, m = valid ? hq_m[r] : 0u, f = valid ? hq_f[r] : 0u;
+            hd += n;
+            wave_lds_sync();
+            if (lane == 0) __hip_atomic_store(&hq_head, hd, __ATOMIC_RELAXED, SCOPE);   // the records are read: their places are free
+            dirty = true;
+            const int x = xy & 0xFFFF, y = xy >> 16;
+            const int hc = octile(x, y, gx, gy);
+            if (valid) g[gidx<GT>(x, y, tw)] = (GT)(f - (uint32_t)hc);
+            uint32_t mv = m & 0xFFu;
+            nd_xy[lane] = xy;
+            nd_mv[lane] = ((m >> 8) & 0xFFu) | ((f - (uint32_t)hc) << 8);     // legal moves | g << 8
+            const uint32_t cnt = (uint32_t)__popc(mv);
+            int base = 0, total = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const unsigned long long mm = __ballot((cnt >> bb) & 1u);
+                base += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)) << bb;
+                total += __popcll(mm) << bb;
+            }
+            while (mv) {
+                const int dd = __ffs((int)mv) - 1;
+                mv &= mv - 1;
+                succ[base++] = (uint16_t)(lane << 3 | dd);
+            }
+            wave_lds_sync();
+            for (int j0 = 0; j0 < total; j0 += 64) {
+                const bool act = j0 + lane < total;
+                const uint32_t sd = act ? succ[j0 + lane] : 0u;
+                const int par = (int)(sd >> 3), d = (int)(sd & 7u);
+                const uint32_t pxy = nd_xy[par], pm = nd_mv[par];
+                const int px = pxy & 0xFFFF, py = pxy >> 16;
+                const int nx = px + (int)((0x2252u >> (2 * d)) & 3u) - 1, ny = py + (int)((0x0A25u >> (2 * d)) & 3u) - 1;
+                const uint32_t fs = (pm >> 8) + (d < 4 ? 10u : 14u) + (uint32_t)octile(nx, ny, gx, gy);
+                if (act) {
+                    const int bb = (int)(fs & 31u);
+                    const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, SCOPE);
+                    if (pos - __hip_atomic_load(&s_head[bb], __ATOMIC_RELAXED, SCOPE) >= cap) __hip_atomic_store(&hq_ovf, 1, __ATOMIC_RELAXED, SCOPE);
+                    else bk[(size_t)bb * cap + (pos & capm)] = entry_pack(nx, ny, d, pm & 0xFFu);
+                }
+            }
+            wave_lds_sync();
+        }
+    } else {
     for (;;) {
         const int b = fcur & 31;
         const uint32_t* bq = bk + (size_t)b * cap;
@@ -353,17 +461,18 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         for (;;) {
             if (lt == lh) {
                 wave_lds_sync();
-                const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
-                const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+                const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head[b], __ATOMIC_RELAXED, SCOPE));
+                const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail[b], __ATOMIC_RELAXED, SCOPE));
                 if (hd == tl) break;
                 const int n = min(tl - hd, REFILL);
                 for (int i = lane; i < n; i += 64) qe[(lt + i) & (CQ - 1)] = bq[(hd + i) & capm];
                 lt += n;
-                if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, SCOPE);
                 wave_lds_sync();
             }
             const int n = min(64, lt - lh);
             npop += n; ++nstep;
+            STAMP(0);   // loop overhead, refills
             if (n <= 8) {
                 // ---- narrow step: 8 lanes per node, lane (sub, d) handles move d of node sub ----
                 const int sub = lane >> 3, d = lane & 7;
@@ -392,7 +501,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #pragma unroll
                 for (int k = 1; k < RUNK; ++k) ra[k - 1] = cell + min(k, lmax - 1) * moff;
                 pop_run_issue(ra, cell, &cl[cix(x, y, bw)], valid && d == 0 ? bit : 0u, rm, pmv, old);
-                const uint32_t prune = entry_prune(e);
+                const uint32_t prune = prune_tbl[(e >> 13) & 63u];
                 pop_run_wait_loads(rm, pmv, old);
                 // while the atomic is under way: this lane's successor(s), should its node be won
                 const bool cand = valid && (((pmv & ~prune) >> d) & 1u);
@@ -404,7 +513,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 atomic_wait(old);
                 old = bcast_group8(old);
                 const bool won = valid && !(old & bit);
-                push_entry(won && cand, ne, df);
+                push_entry(won && cand && (!DUAL || df == 0), ne, df);
 #pragma unroll
                 for (int k = 2; k <= RUNK; ++k) {
                     if (__ballot(won && run >= k) == 0) break;
@@ -412,7 +521,68 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 }
                 nexp += __popcll(__ballot(won && d == 0));
                 if (__ballot(won && x == gx && y == gy)) found = true;
-                if (won && d == 0) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
+                if (DUAL) {
+                    // the moves that leave the level go to wavefront 1 with the node (one byte of the ballot per node)
+                    const unsigned long long later = __ballot(won && cand && df != 0);
+                    hand_over(won && d == 0, x, y, (uint32_t)(later >> (lane & 56)) & 0xFFu, pmv);
+                } else if (won && d == 0) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
+                STAMP(8);   // narrow steps
+            } else if (DUAL) {
+                // ---- wide step, two wavefronts: close the nodes, queue their same-f successors, hand the rest over ----
+                STAMP(0);
+#ifdef ASTAR_STAMPS
+                ++nwide;
+#endif
+                const bool valid = lane < n;
+                const uint32_t e = valid ? qe[(lh + lane) & (CQ - 1)] : 0u;
+                lh += n;
+                const int x = e & 0x1FFF, y = e >> 19;
+                const uint32_t bit = 1u << (x & 31);
+                uint32_t old = 0, pmv;
+                pop_pair_issue(mvs + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
+                const uint32_t prune = prune_tbl[(e >> 13) & 63u];
+                // The moves that keep f: the diagonal towards the goal while both offsets are non-zero (h falls by 14), and
+                // the straight move along the larger offset while the offsets differ (h falls by 10).  Every other move
+                // raises f by 6, 8, 14, 20 or 28.
+                const int dxg = gx - x, dyg = gy - y, adx = abs(dxg), ady = abs(dyg);
+                const int dD = 4 + ((dxg < 0 ? 1 : 0) | (dyg < 0 ? 2 : 0));
+                const int dS = adx > ady ? (dxg < 0 ? 1 : 0) : (dyg < 0 ? 3 : 2);
+                const uint32_t bD = adx >= 1 && ady >= 1 ? 1u << dD : 0u, bS = adx != ady ? 1u << dS : 0u;
+                const int nxD = x + (dxg < 0 ? -1 : 1), nyD = y + (dyg < 0 ? -1 : 1);
+                const int nxS = x + (adx > ady ? (dxg < 0 ? -1 : 1) : 0), nyS = y + (adx > ady ? 0 : (dyg < 0 ? -1 : 1));
+                STAMP(1);
+                pop_pair_wait_load(pmv, old);
+                STAMP(2);
+                const uint32_t cand = valid ? (pmv & ~prune) : 0u;
+                const uint32_t neD = (uint32_t)nyD << 19 | (uint32_t)dD << 13 | (uint32_t)nxD;   // a diagonal arrival has no side flags
+                const uint32_t neS = entry_pack(nxS, nyS, dS, pmv);
+                STAMP(3);
+                atomic_wait(old);
+                STAMP(4);
+                const bool won = valid && !(old & bit);   // duplicates inside one pop: the atomics serialise, one lane wins
+                {
+                    // both same-f entries of a node in one go: the diagonal ones first, then the straight ones
+                    const bool pD = won && (cand & bD), pS = won && (cand & bS);
+                    const unsigned long long mD = __ballot(pD), mS = __ballot(pS);
+                    const int cD = __popcll(mD), c2 = cD + __popcll(mS);
+                    if (c2) {
+                        if (lt - lh + c2 <= CQ) {
+                            if (pD) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mD >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mD, 0u))) & (CQ - 1)] = neD;
+                            if (pS) qe[(lt + cD + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mS, 0u))) & (CQ - 1)] = neS;
+                            lt += c2;
+                        } else {
+                            push_entry(pD, neD, 0);      // ring full: the general path parks them in the level's HBM ring
+                            push_entry(pS, neS, 0);
+                        }
+                    }
+                }
+                STAMP(5);
+                const unsigned long long wm = hand_over(won, x, y, cand & ~(bD | bS), pmv);
+                if (wm) {
+                    nexp += __popcll(wm);
+                    if (__ballot(won && x == gx && y == gy)) found = true;
+                }
+                STAMP(6);
             } else {
                 // ---- wide step: one lane per node, then the legal successors of all nodes 64 at a time ----
                 // The successor list is built while the atomic is still under way, as if every node were won (most are);
@@ -427,7 +597,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const uint32_t bit = 1u << (x & 31);
                 uint32_t old = 0, pmv;
                 pop_pair_issue(mvs + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
-                const uint32_t prune = entry_prune(e);
+                const uint32_t prune = prune_tbl[(e >> 13) & 63u];
                 const int hc = octile(x, y, gx, gy);
                 STAMP(1);   // pop and issue
                 pop_pair_wait_load(pmv, old);
@@ -525,6 +695,14 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             if (--steps_left < 0) ovf = true;
             if (__ballot(ovf)) break;
         }
+        if (DUAL) {
+            // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them
+            STAMP(0);
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl) __builtin_amdgcn_s_sleep(1);
+            wave_lds_sync();
+            if (__hip_atomic_load(&hq_ovf, __ATOMIC_RELAXED, SCOPE)) ovf = true;
+            STAMP(7);
+        }
         if (__ballot(ovf) || found) break;
         // level fcur is exhausted: advance to the next non-empty bucket
         const int rh = __hip_atomic_load(&s_head[lane & 31], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -534,11 +712,15 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         const int r0 = (fcur + 1) & 31;
         const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
         fcur += 1 + (__ffs((int)rot) - 1);
+        STAMP(9);   // next level
     }
+    if (DUAL && lane == 0) __hip_atomic_store(&hq_stop, 1, __ATOMIC_RELAXED, SCOPE);   // wavefront 1 has nothing left (level-end wait): it leaves
+    }   // wavefront 0
+    if (DUAL) __syncthreads();   // wavefront 1's g stores have landed (it waits for them before it reports an empty ring)
 
     const bool overflow = __ballot(ovf) != 0;
     if (overflow) {
-        if (lane == 0) {
+        if (lane == 0 && wv == 0) {
             const int i = atomicAdd(a.ovf_count, 1);
             a.ovf_list[i] = q;
             *a.ovf_sticky = 1;
@@ -597,13 +779,13 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     }
     kcyc = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 #ifdef ASTAR_STAMPS
-    if (lane == 0 && a.Lmax >= 16) {
-        for (int i = 0; i < 8; ++i) path[i] = (int)(stamp[i] >> 10);
-        path[8] = nwide; path[9] = nrounds;
+    if (lane == 0 && wv == 0 && a.Lmax >= 16) {
+        for (int i = 0; i < 12; ++i) path[i] = (int)(stamp[i] >> 10);
+        path[12] = nwide; path[13] = nrounds;
     }
 #endif
     }   // search
-    if (lane == 0) {
+    if (lane == 0 && wv == 0) {
         a.status[q] = out_st; a.len[q] = out_len; a.cost[q] = out_cost;
         a.expanded[q] = nexp; a.expanded[a.nstat + q] = npop; a.expanded[2 * a.nstat + q] = kcyc; a.expanded[3 * a.nstat + q] = nstep;
     }
@@ -617,7 +799,23 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         // queue loop); the queue position is the counter in units of a wavefront
         const int qi = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, 1)) >> 6;
         if (qi >= nq) break;
-        astar_query<GT>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+        astar_query<GT, false>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+    }
+}
+
+// Two wavefronts per query (see astar_query): for batches that leave the chip room for them.
+template <typename GT>
+__global__ void __launch_bounds__(128) astar_kernel_dual(astar_args a) {
+    __shared__ int s_qi;
+    const int nq = a.nq_dev ? *a.nq_dev : a.nq;
+    for (;;) {
+        if (threadIdx.x == 0) s_qi = atomicAdd(a.counter, 64) >> 6;   // the queue position is the counter in units of 64, as above
+        __syncthreads();
+        const int qi = __builtin_amdgcn_readfirstlane(s_qi);
+        __syncthreads();
+        if (qi >= nq) break;
+        astar_query<GT, true>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+        __syncthreads();
     }
 }
 
@@ -678,6 +876,18 @@ static int astar_resident_waves(sc_ctx* ctx) {
     ctx->astar_waves = w;
     return w;
 }
+// Queries the two-wavefront kernel keeps resident (blocks of 128 threads); 0 = switched off (SC_ASTAR_DUAL=0)
+static int astar_resident_dual(sc_ctx* ctx) {
+    if (ctx->astar_dual >= 0) return ctx->astar_dual;
+    int per_cu = 0, n = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel_dual<uint8_t>, 128, 0) == hipSuccess && per_cu > 0 &&
+        hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+        n = per_cu * prop.multiProcessorCount;
+    if (const char* e = getenv("SC_ASTAR_DUAL")) { if (atoi(e) == 0) n = 0; }
+    ctx->astar_dual = n;
+    return n;
+}
 
 static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid, int W, int H, int32_t r2, const int32_t* start,
                      const int32_t* goal, int Q, int Lmax, int32_t* path, int32_t* len, int32_t* cost,
@@ -711,7 +921,9 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     }
     const size_t per_slot = gcells * gsz + bwords * 4 + (size_t)NBUCKET * cap * 4;
     size_t slots = ctx->astar_slot_budget / per_slot;
-    const size_t resident = (size_t)astar_resident_waves(ctx);
+    // two wavefronts per query when the batch leaves room for them (a single call's time is its longest search)
+    const bool dual = !full_g && (size_t)Q <= (size_t)astar_resident_dual(ctx) && (size_t)Q <= slots;
+    const size_t resident = dual ? (size_t)Q : (size_t)astar_resident_waves(ctx);
     if (slots > resident) slots = resident;
     if (slots > (size_t)Q) slots = Q;
     if (slots < 1) slots = 1;
@@ -736,6 +948,7 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
                  cost, status, ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
                  ovf_list, ctr + 1, ctr + 4, Q, tw, bw, gcells, bwords};
     if (full_g) hipLaunchKernelGGL(astar_kernel<uint32_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
+    else if (dual) hipLaunchKernelGGL(astar_kernel_dual<uint8_t>, dim3((unsigned)slots), dim3(128), 0, ctx->stream, a);
     else hipLaunchKernelGGL(astar_kernel<uint8_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
     // retry pass over the overflow list (normally empty: the wavefronts read the count and leave)
     {

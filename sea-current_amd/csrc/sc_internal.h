@@ -53,6 +53,7 @@ struct sc_ctx {
     int64_t gather_bytes = 0;       // bytes every rank received in the last gather
     std::set<const void*> big_lds_done;   // kernels whose dynamic-LDS limit this context has raised on its device
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
+    int astar_dual = -1;   // queries the two-wavefront A* kernel keeps resident (-1: not asked yet, 0: off)
 };
 
 #define SC_HIP(ctx, call)                                                                  \

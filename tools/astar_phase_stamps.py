@@ -8,7 +8,8 @@ import sea_current_amd as sc
 from sea_current_amd import synth
 sc.LIB_PATH = os.path.join(ROOT, "sea-current_amd", "libsc_stamps.so")
 ctx = sc.Context(0)
-names = ["outside wide steps", "pop + issue", "wait load", "successor list", "round-0 prep", "wait atomic", "pushes", "-"]
+names = (["loop overhead, refills", "pop + issue", "wait load", "successor list", "round-0 prep", "wait atomic", "pushes", "-", "narrow steps", "next level", "-", "-"] if os.environ.get("SC_ASTAR_DUAL") == "0" else
+         ["loop overhead, refills", "pop + issue + geometry", "wait load", "entries", "wait atomic", "same-f pushes", "hand-over", "level-end wait", "narrow steps", "next level", "-", "-"])
 for fam in sys.argv[1].split(","):
     occ = synth.salt_grid(1024, 1024, 0.05) if fam == "salt05" else synth.salt_grid(1024, 1024, 0.2) if fam == "salt20" else synth.block_grid(1024, 1024, 0.2)
     d2 = ctx.edt(torch.from_numpy(occ).cuda()); torch.cuda.synchronize()
@@ -17,8 +18,8 @@ for fam in sys.argv[1].split(","):
     ex, pop, kc, stp = ctx.astar_debug_stats(1024)
     path = out["path"].cpu().numpy()
     for k in np.argsort(-kc)[:3]:
-        st = path[k, :10].astype(np.int64)
-        nwide, nrounds = st[8], st[9]
+        st = path[k, :14].astype(np.int64)
+        nwide, nrounds = st[12], st[13]
         print(fam, "query %d: %d kcycles, %d steps of which %d wide (%d push rounds), %d popped, %d expanded" % (k, kc[k], stp[k], nwide, nrounds, pop[k], ex[k]))
-        for i in range(7):
+        for i in range(10):
             print("     %-20s %7d kcycles  %5.1f %%   %6.0f cycles per wide step" % (names[i], st[i], 100.0 * st[i] / max(kc[k], 1), st[i] * 1024.0 / max(nwide, 1)))
