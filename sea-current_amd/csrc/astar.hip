@@ -350,7 +350,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         bool spill = false;
         if (m0) {
             const int cnt = __popcll(m0);
-            if (lt - lh + cnt <= CQ) {
+            if (__builtin_expect(lt - lh + cnt <= CQ, 1)) {
                 if (same) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
                     qe[(lt + rank) & (CQ - 1)] = ne;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         if (act && (df != 0 || spill)) {
             const int bb = (fcur + df) & 31;
             const int pos = __hip_atomic_fetch_add(&s_tail[bb], 1, __ATOMIC_RELAXED, SCOPE);
-            if (pos - __hip_atomic_load(&s_head[bb], __ATOMIC_RELAXED, SCOPE) >= cap) ovf = true;
+            if (__builtin_expect(pos - __hip_atomic_load(&s_head[bb], __ATOMIC_RELAXED, SCOPE) >= cap, 0)) ovf = true;
             else bk[(size_t)bb * cap + (pos & capm)] = ne;
         }
         lt = __builtin_amdgcn_readfirstlane(lt);   // wave-uniform by construction; says so to the compiler
@@ -373,7 +373,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         const unsigned long long wm = __ballot(rec);
         if (wm) {
             const int cnt = __popcll(wm);
-            while (hq_tl + cnt - hq_hd > HQ) {     // wavefront 1 is a whole ring behind (as far as we know): look again
+            while (__builtin_expect(hq_tl + cnt - hq_hd > HQ, 0)) {     // wavefront 1 is a whole ring behind (as far as we know): look again
                 hq_hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_head, __ATOMIC_RELAXED, SCOPE));
                 if (hq_tl + cnt - hq_hd > HQ) __builtin_amdgcn_s_sleep(1);
             }
@@ -459,7 +459,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         const uint32_t* bq = bk + (size_t)b * cap;
         // drain everything with f == fcur: the LDS ring, refilled from what earlier levels left in HBM
         for (;;) {
-            if (lt == lh) {
+            if (__builtin_expect(lt == lh, 0)) {
                 wave_lds_sync();
                 const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head[b], __ATOMIC_RELAXED, SCOPE));
                 const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail[b], __ATOMIC_RELAXED, SCOPE));
@@ -529,7 +529,6 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 STAMP(8);   // narrow steps
             } else if (DUAL) {
                 // ---- wide step, two wavefronts: close the nodes, queue their same-f successors, hand the rest over ----
-                STAMP(0);
 #ifdef ASTAR_STAMPS
                 ++nwide;
 #endif
@@ -550,15 +549,11 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const uint32_t bD = adx >= 1 && ady >= 1 ? 1u << dD : 0u, bS = adx != ady ? 1u << dS : 0u;
                 const int nxD = x + (dxg < 0 ? -1 : 1), nyD = y + (dyg < 0 ? -1 : 1);
                 const int nxS = x + (adx > ady ? (dxg < 0 ? -1 : 1) : 0), nyS = y + (adx > ady ? 0 : (dyg < 0 ? -1 : 1));
-                STAMP(1);
                 pop_pair_wait_load(pmv, old);
-                STAMP(2);
                 const uint32_t cand = valid ? (pmv & ~prune) : 0u;
                 const uint32_t neD = (uint32_t)nyD << 19 | (uint32_t)dD << 13 | (uint32_t)nxD;   // a diagonal arrival has no side flags
                 const uint32_t neS = entry_pack(nxS, nyS, dS, pmv);
-                STAMP(3);
                 atomic_wait(old);
-                STAMP(4);
                 const bool won = valid && !(old & bit);   // duplicates inside one pop: the atomics serialise, one lane wins
                 {
                     // both same-f entries of a node in one go: the diagonal ones first, then the straight ones
@@ -566,7 +561,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     const unsigned long long mD = __ballot(pD), mS = __ballot(pS);
                     const int cD = __popcll(mD), c2 = cD + __popcll(mS);
                     if (c2) {
-                        if (lt - lh + c2 <= CQ) {
+                        if (__builtin_expect(lt - lh + c2 <= CQ, 1)) {
                             if (pD) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mD >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mD, 0u))) & (CQ - 1)] = neD;
                             if (pS) qe[(lt + cD + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mS, 0u))) & (CQ - 1)] = neS;
                             lt += c2;
@@ -576,7 +571,6 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                         }
                     }
                 }
-                STAMP(5);
                 const unsigned long long wm = hand_over(won, x, y, cand & ~(bD | bS), pmv);
                 if (wm) {
                     nexp += __popcll(wm);
@@ -693,7 +687,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             wave_lds_sync();
             MARK(1, steps_left); MARK(2, fcur); MARK(3, nexp); MARK(4, lt - lh);
             if (--steps_left < 0) ovf = true;
-            if (__ballot(ovf)) break;
+            if (__builtin_expect(__ballot(ovf) != 0, 0)) break;
         }
         if (DUAL) {
             // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them

@@ -9,7 +9,7 @@ from sea_current_amd import synth
 sc.LIB_PATH = os.path.join(ROOT, "sea-current_amd", "libsc_stamps.so")
 ctx = sc.Context(0)
 names = (["loop overhead, refills", "pop + issue", "wait load", "successor list", "round-0 prep", "wait atomic", "pushes", "-", "narrow steps", "next level", "-", "-"] if os.environ.get("SC_ASTAR_DUAL") == "0" else
-         ["loop overhead, refills", "pop + issue + geometry", "wait load", "entries", "wait atomic", "same-f pushes", "hand-over", "level-end wait", "narrow steps", "next level", "-", "-"])
+         ["loop overhead, refills", "-", "-", "-", "-", "-", "wide steps", "level-end wait", "narrow steps", "next level", "-", "-"])
 for fam in sys.argv[1].split(","):
     occ = synth.salt_grid(1024, 1024, 0.05) if fam == "salt05" else synth.salt_grid(1024, 1024, 0.2) if fam == "salt20" else synth.block_grid(1024, 1024, 0.2)
     d2 = ctx.edt(torch.from_numpy(occ).cuda()); torch.cuda.synchronize()
