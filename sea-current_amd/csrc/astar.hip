@@ -473,7 +473,59 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             const int n = min(64, lt - lh);
             npop += n; ++nstep;
             STAMP(0);   // loop overhead, refills
-            if (n <= 8) {
+            if (DUAL && n <= 16) {
+                // ---- narrow step, two wavefronts: lane (node, direction, k) for the two same-f directions of a node and
+                // k = 0 .. KL-1 cells along them (KL = 8 for up to 4 nodes, 4 / 2 / 1 for up to 8 / 16 / 32): ONE load per lane (the
+                // legal-move byte of cell k; cell 0 is the node), the run of a direction is the number of leading lanes of its
+                // group whose cell continues legally, and every queued cell of every run goes into the ring in one append.
+                // The moves that leave the level go to wavefront 1 with the node, as in the wide step.
+                const int kl = n <= 4 ? 3 : n <= 8 ? 2 : n <= 16 ? 1 : 0, KL = 1 << kl, GL = 2 * KL;   // log2 lanes per direction; lanes per direction, per node
+                const int sub = lane >> (kl + 1), j = (lane >> kl) & 1, k = lane & (KL - 1);
+                const bool valid = sub < n;
+                const uint32_t e = valid ? qe[(lh + sub) & (CQ - 1)] : 0u;
+                lh += n;
+                const int x = e & 0x1FFF, y = e >> 19;
+                const uint32_t bit = 1u << (x & 31);
+                const int dxg = gx - x, dyg = gy - y, adx = abs(dxg), ady = abs(dyg);
+                const int dD = 4 + ((dxg < 0 ? 1 : 0) | (dyg < 0 ? 2 : 0));
+                const int dS = adx > ady ? (dxg < 0 ? 1 : 0) : (dyg < 0 ? 3 : 2);
+                const uint32_t bD = adx >= 1 && ady >= 1 ? 1u << dD : 0u, bS = adx != ady ? 1u << dS : 0u;
+                const int d = j ? dS : dD;
+                const bool has = valid && (j ? bS : bD) != 0u;
+                const int lgeom = j ? abs(adx - ady) : min(adx, ady);            // cells that keep f along d (>= 1 when `has`)
+                const int ddx_ = (int)((0x2252u >> (2 * d)) & 3u) - 1, ddy_ = (int)((0x0A25u >> (2 * d)) & 3u) - 1;
+                const uint8_t* const addr = mvs + (y * W + x) + (has ? min(k, lgeom - 1) : 0) * (ddy_ * W + ddx_);   // invalid lanes read cell 0: harmless
+                const bool head = valid && j == 0 && k == 0;                      // the node's own lane: atomic, hand-over
+                uint32_t old = 0, byte;
+                pop_pair_issue(addr, &cl[cix(x, y, bw)], head ? bit : 0u, byte, old);
+                const uint32_t prune = prune_tbl[(e >> 13) & 63u];
+                pop_pair_wait_load(byte, old);
+                // the link cell k -> cell k + 1 along d (from the node itself: unless pruned)
+                const bool link = has && k < lgeom && ((byte >> d) & 1u) && (k > 0 || !((prune >> d) & 1u));
+                const unsigned long long lm = __ballot(link);
+                const uint32_t grp = (uint32_t)(lm >> (lane & ~(KL - 1))) & ((1u << KL) - 1u);
+                const int run = __ffs((int)~grp) - 1;                             // leading lanes of the group that link
+                const uint32_t ne = entry_pack(x + (k + 1) * ddx_, y + (k + 1) * ddy_, d, byte) | (k + 1 < run ? E_RUN : 0u);
+                atomic_wait(old);
+                const bool won1 = head && !(old & bit);
+                const unsigned long long wm1 = __ballot(won1);
+                const bool act = ((wm1 >> (lane & ~(GL - 1))) & 1ull) && k < run;
+                {
+                    const unsigned long long ma = __ballot(act);
+                    if (ma) {
+                        const int c = __popcll(ma);
+                        if (__builtin_expect(lt - lh + c <= CQ, 1)) {
+                            if (act) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u))) & (CQ - 1)] = ne;
+                            lt += c;
+                        } else push_entry(act, ne, 0);                            // ring full: the general path parks them in the level's HBM ring
+                    }
+                }
+                if (hand_over(won1, x, y, (byte & ~prune) & ~(bD | bS), byte)) {
+                    nexp += __popcll(wm1);
+                    if (__ballot(won1 && x == gx && y == gy)) found = true;
+                }
+                STAMP(8);   // narrow steps
+            } else if (n <= 8) {
                 // ---- narrow step: 8 lanes per node, lane (sub, d) handles move d of node sub ----
                 const int sub = lane >> 3, d = lane & 7;
                 const bool valid = sub < n;
