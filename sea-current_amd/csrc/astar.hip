@@ -235,6 +235,29 @@ __device__ __forceinline__ void atomic_wait_but(uint32_t& old, uint32_t (&rm)[RU
 }
 __device__ __forceinline__ void pop_pair_wait_load(uint32_t& pmv, uint32_t& old) { asm volatile("s_waitcnt vmcnt(1)" : "+v"(pmv), "+v"(old) : : "memory"); }
 
+// Two-wavefront kernel: a query's closed bitmap has ONE writer (its wavefront 0), so the test-and-set of a popped node need
+// not be a returning atomic (about twice a load's latency): the word is LOADED (agent scope: from L2) beside the legal-move
+// byte, duplicates inside the step are settled in LDS while the loads are under way (dup_settle), and the bits of the
+// nodes that were won are set by an atomic OR nobody waits for: the OR of one step and the load of a later one travel the
+// same path to the same L2 channel in issue order, so the load sees the bit without waiting for the OR's acknowledgement
+// (waiting for it put the atomic's latency back on the path; a stale word would show as a node expanded twice, which
+// the expansion counts in tests/test_gpu_astar.py, equal to the oracle's query by query, would catch).
+__device__ __forceinline__ void pop_loads_issue(const uint8_t* mv_addr, const uint32_t* w_addr, uint32_t& byte, uint32_t& word) {
+    asm volatile("global_load_ubyte %0, %2, off\n\t"
+                 "global_load_dword %1, %3, off sc1"
+                 : "=&v"(byte), "=&v"(word) : "v"(mv_addr), "v"(w_addr) : "memory");
+}
+__device__ __forceinline__ void pop_loads_wait(uint32_t& byte, uint32_t& word) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(byte), "+v"(word) : : "memory"); }
+__device__ __forceinline__ void masked_or_noret(uint32_t* addr, uint32_t bits) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmp_ne_u32_e32 vcc, 0, %[b]\n\t"
+                 "s_and_b64 exec, %[sv], vcc\n\t"
+                 "global_atomic_or %[a], %[b], off\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv) : [a] "v"(addr), [b] "v"(bits) : "vcc", "scc", "memory");
+}
+
 // value of lane 8k (the only non-zero one of its group) in all 8 lanes of the group
 __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
     const uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xF, 0xF, false);
@@ -274,6 +297,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint32_t nd_mv[64];
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
+    __shared__ uint8_t dup_tbl[DUAL ? 1024 : 1];   // DUAL: who pops cell (x + 32 y) mod 1024 in this step
     __shared__ uint32_t hq_xy[DUAL ? HQ : 1], hq_m[DUAL ? HQ : 1], hq_f[DUAL ? HQ : 1];   // hand-over ring: node, moves | legal moves << 8, f
     __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf;
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
@@ -330,7 +354,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
     long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = t_begin;
-    int nwide = 0, nrounds = 0;
+    int nwide = 0, nrounds = 0, n_qfull = 0, n_lvl = 0, b_batches = 0, b_records = 0, b_idle = 0;
 #endif
     // Every step pops at least one entry and a search pushes at most 8 entries per cell: a bound that a correct
     // search cannot reach, so that no wavefront can spin forever whatever the state of its scratch memory.
@@ -375,7 +399,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             const int cnt = __popcll(wm);
             while (__builtin_expect(hq_tl + cnt - hq_hd > HQ, 0)) {     // wavefront 1 is a whole ring behind (as far as we know): look again
                 hq_hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_head, __ATOMIC_RELAXED, SCOPE));
-                if (hq_tl + cnt - hq_hd > HQ) __builtin_amdgcn_s_sleep(1);
+                if (hq_tl + cnt - hq_hd > HQ) {
+                    __builtin_amdgcn_s_sleep(1);
+#ifdef ASTAR_STAMPS
+                    ++n_qfull;
+#endif
+                }
             }
             if (rec) {
                 const int r = (hq_tl + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))) & (HQ - 1);
@@ -388,6 +417,33 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             if (lane == 0) __hip_atomic_store(&hq_tail, hq_tl, __ATOMIC_RELAXED, SCOPE);
         }
         return wm;
+    };
+    // DUAL, wavefront 0: among the `is` lanes (each pops node (hx, hy), entry he) find one representative per node.
+    // 0 = representative, 1 = the same node is popped by another lane of this step (dropped, as a lost atomic would be),
+    // 2 = lost its table slot to a DIFFERENT node: its entry goes back into the ring for the next step.
+    auto dup_settle = [&](const bool is, const int hx, const int hy, const uint32_t he) {
+        const int h = (hx + 32 * hy) & 1023;
+        if (is) dup_tbl[h] = (uint8_t)lane;
+        wave_lds_sync();
+        const int w = is ? (int)dup_tbl[h] : lane;
+        int res = 0;
+        if (__ballot(w != lane)) {
+            const uint32_t key = (uint32_t)hy << 16 | (uint32_t)hx;
+            const uint32_t okey = (uint32_t)__shfl((int)key, w);
+            res = w == lane ? 0 : (okey == key ? 1 : 2);
+            const bool back = res == 2;
+            const unsigned long long mb = __ballot(back);
+            if (mb) {
+                const int c = __popcll(mb);
+                if (__builtin_expect(lt - lh + c <= CQ, 1)) {
+                    if (back) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))) & (CQ - 1)] = he;
+                    lt += c;
+                } else push_entry(back, he, 0);
+                npop -= c;   // they are popped again
+            }
+        }
+        wave_lds_sync();
+        return res;
     };
     if (DUAL && wv == 1) {
         // ---- wavefront 1: g and the later-level successors of the nodes wavefront 0 has won ----
@@ -406,8 +462,14 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 }
                 if (stop) break;
                 __builtin_amdgcn_s_sleep(1);
+#ifdef ASTAR_STAMPS
+                ++b_idle;
+#endif
                 continue;
             }
+#ifdef ASTAR_STAMPS
+            ++b_batches; b_records += min(tl - hd, 64);
+#endif
             const int n = min(tl - hd, 64);
             const bool valid = lane < n;
             const int r = (hd + lane) & (HQ - 1);
@@ -453,6 +515,9 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             }
             wave_lds_sync();
         }
+#ifdef ASTAR_STAMPS
+        if (lane == 0 && a.Lmax >= 32) { path[16] = b_batches; path[17] = b_records; path[18] = b_idle; }
+#endif
     } else {
     for (;;) {
         const int b = fcur & 31;
@@ -496,18 +561,20 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int ddx_ = (int)((0x2252u >> (2 * d)) & 3u) - 1, ddy_ = (int)((0x0A25u >> (2 * d)) & 3u) - 1;
                 const uint8_t* const addr = mvs + (y * W + x) + (has ? min(k, lgeom - 1) : 0) * (ddy_ * W + ddx_);   // invalid lanes read cell 0: harmless
                 const bool head = valid && j == 0 && k == 0;                      // the node's own lane: atomic, hand-over
-                uint32_t old = 0, byte;
-                pop_pair_issue(addr, &cl[cix(x, y, bw)], head ? bit : 0u, byte, old);
+                uint32_t old, byte;
+                uint32_t* const wa = &cl[cix(x, y, bw)];
+                pop_loads_issue(addr, wa, byte, old);
                 const uint32_t prune = prune_tbl[(e >> 13) & 63u];
-                pop_pair_wait_load(byte, old);
+                const int dup = dup_settle(head, x, y, e);
+                pop_loads_wait(byte, old);
                 // the link cell k -> cell k + 1 along d (from the node itself: unless pruned)
                 const bool link = has && k < lgeom && ((byte >> d) & 1u) && (k > 0 || !((prune >> d) & 1u));
                 const unsigned long long lm = __ballot(link);
                 const uint32_t grp = (uint32_t)(lm >> (lane & ~(KL - 1))) & ((1u << KL) - 1u);
                 const int run = __ffs((int)~grp) - 1;                             // leading lanes of the group that link
                 const uint32_t ne = entry_pack(x + (k + 1) * ddx_, y + (k + 1) * ddy_, d, byte) | (k + 1 < run ? E_RUN : 0u);
-                atomic_wait(old);
-                const bool won1 = head && !(old & bit);
+                const bool won1 = head && dup == 0 && !(old & bit);
+                masked_or_noret(wa, won1 ? bit : 0u);
                 const unsigned long long wm1 = __ballot(won1);
                 const bool act = ((wm1 >> (lane & ~(GL - 1))) & 1ull) && k < run;
                 {
@@ -589,8 +656,10 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 lh += n;
                 const int x = e & 0x1FFF, y = e >> 19;
                 const uint32_t bit = 1u << (x & 31);
-                uint32_t old = 0, pmv;
-                pop_pair_issue(mvs + (y * W + x), &cl[cix(x, y, bw)], valid ? bit : 0u, pmv, old);   // invalid lanes read cell 0: harmless
+                uint32_t old, pmv;
+                uint32_t* const wa = &cl[cix(x, y, bw)];
+                pop_loads_issue(mvs + (y * W + x), wa, pmv, old);   // invalid lanes read cell 0: harmless
+                const int dup = dup_settle(valid, x, y, e);
                 const uint32_t prune = prune_tbl[(e >> 13) & 63u];
                 // The moves that keep f: the diagonal towards the goal while both offsets are non-zero (h falls by 14), and
                 // the straight move along the larger offset while the offsets differ (h falls by 10).  Every other move
@@ -601,12 +670,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const uint32_t bD = adx >= 1 && ady >= 1 ? 1u << dD : 0u, bS = adx != ady ? 1u << dS : 0u;
                 const int nxD = x + (dxg < 0 ? -1 : 1), nyD = y + (dyg < 0 ? -1 : 1);
                 const int nxS = x + (adx > ady ? (dxg < 0 ? -1 : 1) : 0), nyS = y + (adx > ady ? 0 : (dyg < 0 ? -1 : 1));
-                pop_pair_wait_load(pmv, old);
+                pop_loads_wait(pmv, old);
                 const uint32_t cand = valid ? (pmv & ~prune) : 0u;
                 const uint32_t neD = (uint32_t)nyD << 19 | (uint32_t)dD << 13 | (uint32_t)nxD;   // a diagonal arrival has no side flags
                 const uint32_t neS = entry_pack(nxS, nyS, dS, pmv);
-                atomic_wait(old);
-                const bool won = valid && !(old & bit);   // duplicates inside one pop: the atomics serialise, one lane wins
+                const bool won = valid && dup == 0 && !(old & bit);
+                masked_or_noret(wa, won ? bit : 0u);
                 {
                     // both same-f entries of a node in one go: the diagonal ones first, then the straight ones
                     const bool pD = won && (cand & bD), pS = won && (cand & bS);
@@ -744,7 +813,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         if (DUAL) {
             // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them
             STAMP(0);
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl) __builtin_amdgcn_s_sleep(1);
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl) {
+                __builtin_amdgcn_s_sleep(1);
+#ifdef ASTAR_STAMPS
+                ++n_lvl;
+#endif
+            }
             wave_lds_sync();
             if (__hip_atomic_load(&hq_ovf, __ATOMIC_RELAXED, SCOPE)) ovf = true;
             STAMP(7);
@@ -827,7 +901,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
     if (lane == 0 && wv == 0 && a.Lmax >= 16) {
         for (int i = 0; i < 12; ++i) path[i] = (int)(stamp[i] >> 10);
-        path[12] = nwide; path[13] = nrounds;
+        path[12] = nwide; path[13] = nrounds; path[14] = n_qfull; path[15] = n_lvl;
     }
 #endif
     }   // search

@@ -18,7 +18,8 @@ for fam in sys.argv[1].split(","):
     ex, pop, kc, stp = ctx.astar_debug_stats(1024)
     path = out["path"].cpu().numpy()
     for k in np.argsort(-kc)[:3]:
-        st = path[k, :14].astype(np.int64)
+        st = path[k, :19].astype(np.int64)
+        print('   wavefront 0: %d sleeps on a full hand-over ring, %d sleeps at level ends | wavefront 1: %d batches, %d records, %d idle polls' % (st[14], st[15], st[16], st[17], st[18]))
         nwide, nrounds = st[12], st[13]
         print(fam, "query %d: %d kcycles, %d steps of which %d wide (%d push rounds), %d popped, %d expanded" % (k, kc[k], stp[k], nwide, nrounds, pop[k], ex[k]))
         for i in range(10):
