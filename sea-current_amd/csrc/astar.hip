@@ -44,6 +44,10 @@
 // recorded on the device and the overflowed queries are rerun by a second launch that is always
 // enqueued behind the first, with 16x the ring space per query (a handful of wavefronts; it returns
 // at once when the list is empty).
+//
+// Two kernels share astar_query: astar_kernel (one wavefront per query: the saturated rate, bound by instruction
+// issue) for batches larger than the chip holds, astar_kernel_dual (two wavefronts per query, see astar_query) for
+// batches of up to ~2000 queries, where the time of a call is the time of its longest search.
 #include "sc_internal.h"
 #include <stdlib.h>
 
@@ -592,7 +596,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     if (__ballot(won1 && x == gx && y == gy)) found = true;
                 }
                 STAMP(8);   // narrow steps
-            } else if (n <= 8) {
+            } else if (!DUAL && n <= 8) {
                 // ---- narrow step: 8 lanes per node, lane (sub, d) handles move d of node sub ----
                 const int sub = lane >> 3, d = lane & 7;
                 const bool valid = sub < n;
@@ -632,7 +636,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 atomic_wait(old);
                 old = bcast_group8(old);
                 const bool won = valid && !(old & bit);
-                push_entry(won && cand && (!DUAL || df == 0), ne, df);
+                push_entry(won && cand, ne, df);
 #pragma unroll
                 for (int k = 2; k <= RUNK; ++k) {
                     if (__ballot(won && run >= k) == 0) break;
@@ -640,11 +644,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 }
                 nexp += __popcll(__ballot(won && d == 0));
                 if (__ballot(won && x == gx && y == gy)) found = true;
-                if (DUAL) {
-                    // the moves that leave the level go to wavefront 1 with the node (one byte of the ballot per node)
-                    const unsigned long long later = __ballot(won && cand && df != 0);
-                    hand_over(won && d == 0, x, y, (uint32_t)(later >> (lane & 56)) & 0xFFu, pmv);
-                } else if (won && d == 0) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
+                if (won && d == 0) g[gidx<GT>(x, y, tw)] = (GT)(fcur - hc);
                 STAMP(8);   // narrow steps
             } else if (DUAL) {
                 // ---- wide step, two wavefronts: close the nodes, queue their same-f successors, hand the rest over ----
