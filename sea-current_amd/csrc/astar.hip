@@ -321,7 +321,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     if (bad) out_st = SC_Q_BAD_ENDPOINT;
     else if (s == t) {
         if (lane == 0 && wv == 0) path[0] = s;
-        out_len = 1; out_cost = 0;
+        out_len = 1; out_cost = 0; nexp = 1;   // the oracle counts the start node of a trivial query as expanded
     } else {
     MARK(0, 1);
     const int tw = a.tw, bw = a.bw;

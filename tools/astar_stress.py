@@ -11,7 +11,7 @@ oracle.build()
 ctx = sc.Context(0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(2024)
-nq = nfound = 0
+nq = nfound = nbad_ex = 0
 for r in range(rounds):
     W, H = int(rng.integers(9, 400)), int(rng.integers(9, 400))
     fam = rng.integers(0, 3)
@@ -43,7 +43,14 @@ for r in range(rounds):
     for q in range(Q):
         if ref["status"][q] == 0:
             assert np.array_equal(got["path"][q, :ref["len"][q]], ref["path"][q, :ref["len"][q]]), (r, W, H, fam, r2, q)
+    ex = ctx.astar_debug_stats(Q)[0]
+    if not np.array_equal(ex, ref["expanded"]):
+        bad = np.flatnonzero(ex != ref["expanded"])
+        print("expansion counts differ: round", r, (W, H), "family", int(fam), "r2", r2, "queries", bad[:8].tolist(), "status", ref["status"][bad[:8]].tolist(),
+              "gpu", ex[bad[:8]].tolist(), "oracle", ref["expanded"][bad[:8]].tolist(), "cost", ref["cost"][bad[:8]].tolist(), flush=True)
+        nbad_ex += 1
     nq += Q; nfound += int((ref["status"] == 0).sum())
     if r % 25 == 0:
         print("round", r, "ok", flush=True)
-print("stress ok:", nq, "queries,", nfound, "with paths")
+print("stress ok:", nq, "queries,", nfound, "with paths;", nbad_ex, "rounds with differing expansion counts")
+assert nbad_ex == 0
