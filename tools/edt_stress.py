@@ -13,7 +13,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(7)
 cells = 0
 for r in range(rounds):
-    W = int(rng.choice([rng.integers(1, 70), rng.integers(70, 1025), rng.integers(1025, 2700), 1024, 512, 1023, 1025, 2048]))
+    W = int(rng.choice([rng.integers(1, 70), rng.integers(70, 1025), rng.integers(1025, 2700), rng.integers(2700, 6000), 1024, 512, 1023, 1025, 2048, 4096]))
     H = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), 32, 33, 31, 64]))
     B = int(rng.choice([1, 1, 2, 5]))
     p = float(rng.choice([0.0, 1e-5, 1e-4, 1e-3, 0.01, 0.05, 0.2, 0.5, 0.95]))
