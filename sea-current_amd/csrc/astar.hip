@@ -302,8 +302,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
     __shared__ uint8_t dup_tbl[DUAL ? 1024 : 1];   // DUAL: who pops cell (x + 32 y) mod 1024 in this step
-    __shared__ uint32_t hq_xy[DUAL ? HQ : 1], hq_m[DUAL ? HQ : 1], hq_f[DUAL ? HQ : 1];   // hand-over ring: node, moves | legal moves << 8, f
-    __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf;
+    __shared__ uint32_t hq_xy[DUAL ? HQ : 1], hq_m[DUAL ? HQ : 1];   // hand-over ring: node, moves | legal moves << 8
+    __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
     const int lane = threadIdx.x & 63;
     const int wv = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     int fcur = octile(sx, sy, gx, gy);
     if (wv == 0 && lane == 0) {
         qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
-        hq_tail = 0; hq_head = 0; hq_clean = 0; hq_stop = 0; hq_ovf = 0;
+        hq_tail = 0; hq_head = 0; hq_clean = 0; hq_stop = 0; hq_ovf = 0; hq_fcur = fcur; hq_found = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bitmap is clear before the first atomic OR
     wave_lds_sync();
@@ -414,7 +414,6 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int r = (hq_tl + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))) & (HQ - 1);
                 hq_xy[r] = (uint32_t)hy << 16 | (uint32_t)hx;
                 hq_m[r] = hm | hp << 8;
-                hq_f[r] = (uint32_t)fcur;
             }
             hq_tl += cnt;
             wave_lds_sync();
@@ -477,7 +476,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             const int n = min(tl - hd, 64);
             const bool valid = lane < n;
             const int r = (hd + lane) & (HQ - 1);
-            const uint32_t xy = valid ? hq_xy[r] : 0u, m = valid ? hq_m[r] : 0u, f = valid ? hq_f[r] : 0u;
+            const uint32_t xy = valid ? hq_xy[r] : 0u, m = valid ? hq_m[r] : 0u;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_fcur, __ATOMIC_RELAXED, SCOPE));
             hd += n;
             wave_lds_sync();
             if (lane == 0) __hip_atomic_store(&hq_head, hd, __ATOMIC_RELAXED, SCOPE);   // the records are read: their places are free
@@ -485,6 +485,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             const int x = xy & 0xFFFF, y = xy >> 16;
             const int hc = octile(x, y, gx, gy);
             if (valid) g[gidx<GT>(x, y, tw)] = (GT)(f - (uint32_t)hc);
+            if (__ballot(valid && x == gx && y == gy) && lane == 0) __hip_atomic_store(&hq_found, 1, __ATOMIC_RELAXED, SCOPE);   // the goal has been expanded
             uint32_t mv = m & 0xFFu;
             nd_xy[lane] = xy;
             nd_mv[lane] = ((m >> 8) & 0xFFu) | ((f - (uint32_t)hc) << 8);     // legal moves | g << 8
@@ -591,10 +592,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                         } else push_entry(act, ne, 0);                            // ring full: the general path parks them in the level's HBM ring
                     }
                 }
-                if (hand_over(won1, x, y, (byte & ~prune) & ~(bD | bS), byte)) {
-                    nexp += __popcll(wm1);
-                    if (__ballot(won1 && x == gx && y == gy)) found = true;
-                }
+                hand_over(won1, x, y, (byte & ~prune) & ~(bD | bS), byte);
+                nexp += __popcll(wm1);
                 STAMP(8);   // narrow steps
             } else if (!DUAL && n <= 8) {
                 // ---- narrow step: 8 lanes per node, lane (sub, d) handles move d of node sub ----
@@ -692,11 +691,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                         }
                     }
                 }
-                const unsigned long long wm = hand_over(won, x, y, cand & ~(bD | bS), pmv);
-                if (wm) {
-                    nexp += __popcll(wm);
-                    if (__ballot(won && x == gx && y == gy)) found = true;
-                }
+                nexp += __popcll(hand_over(won, x, y, cand & ~(bD | bS), pmv));
                 STAMP(6);
             } else {
                 // ---- wide step: one lane per node, then the legal successors of all nodes 64 at a time ----
@@ -808,7 +803,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             wave_lds_sync();
             MARK(1, steps_left); MARK(2, fcur); MARK(3, nexp); MARK(4, lt - lh);
             if (--steps_left < 0) ovf = true;
-            if (__builtin_expect(__ballot(ovf) != 0, 0)) break;
+            if (__builtin_expect(DUAL ? steps_left < 0 : __ballot(ovf) != 0, 0)) break;
         }
         if (DUAL) {
             // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them
@@ -821,6 +816,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             }
             wave_lds_sync();
             if (__hip_atomic_load(&hq_ovf, __ATOMIC_RELAXED, SCOPE)) ovf = true;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_found, __ATOMIC_RELAXED, SCOPE))) found = true;
             STAMP(7);
         }
         if (__ballot(ovf) || found) break;
@@ -832,6 +828,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         const int r0 = (fcur + 1) & 31;
         const uint32_t rot = r0 ? (nonempty >> r0) | (nonempty << (32 - r0)) : nonempty;
         fcur += 1 + (__ffs((int)rot) - 1);
+        if (DUAL && lane == 0) __hip_atomic_store(&hq_fcur, fcur, __ATOMIC_RELAXED, SCOPE);   // the ring is empty: wavefront 1 reads it with the next records
         STAMP(9);   // next level
     }
     if (DUAL && lane == 0) __hip_atomic_store(&hq_stop, 1, __ATOMIC_RELAXED, SCOPE);   // wavefront 1 has nothing left (level-end wait): it leaves
