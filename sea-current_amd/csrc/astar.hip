@@ -464,7 +464,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     dirty = false;
                 }
                 if (stop) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
 #ifdef ASTAR_STAMPS
                 ++b_idle;
 #endif
