@@ -158,7 +158,7 @@ def main():
         goal = torch.from_numpy(np.tile(g_h, G)).to(dev)
         qgrid = torch.from_numpy(np.repeat(np.arange(G, dtype=np.int32), Qloc)).to(dev)
         outs = [alloc_out(G) for _ in range(depth)]
-        gath = [[None] * G for _ in range(depth)]
+        gath = [None] * depth
         tp_args = None
         if with_toppra:
             pl = synth.toppra_plans(Qloc, dof=6, first=q0)
@@ -181,9 +181,11 @@ def main():
                     c.astar_batch(d2s[j][0], start, goal, r2=0, Lmax=args.lmax, out=outs[j])
                 else:
                     c.astar_batch_multi(d2s[j], qgrid, start, goal, r2=0, Lmax=args.lmax, out=outs[j])
+                if use_gather:
+                    # one exchange per library call: this rank's G x Qloc results (step-major) to every rank; in the gathered
+                    # arrays rank r's block is [r G Qloc, (r + 1) G Qloc), i.e. step k of rank r starts at (r G + k) Qloc
+                    gath[j] = c.allgather_paths(outs[j], G * Qtot, G * cap_cells, bufs=gath[j])
                 for k in range(G):
-                    if use_gather:
-                        gath[j][k] = c.allgather_paths(view(outs[j], k), Qtot, cap_cells, bufs=gath[j][k])
                     if with_toppra:
                         tp = c.toppra(*tp_args, N=200)
                         tp_last[0] = (tp, c.toppra_sample(tp_args[0], tp_args[1], tp_args[2], tp_args[3], tp["x"], tp["t"], 0.02, 512))
@@ -224,7 +226,7 @@ def main():
                           "found": int((st == 0).sum()), "no_path": int((st == 1).sum()), "ring_overflow": int((st == 4).sum()),
                           "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
                    steps=steps, group=G,
-                   _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st, d2=d2s[0][0], gath=gath[0][0]))
+                   _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st, d2=d2s[0][0], gath=gath[0]))
         if with_toppra:
             res["toppra_ok"] = int((tp_last[0][0]["status"] == 0).sum())
         return res
@@ -245,11 +247,19 @@ def main():
         cells = ga["cells"].cpu().numpy()
         mine_p = out["path"].cpu().numpy()
         mine_l = out["len"].cpu().numpy()
-        ok = bool(np.array_equal(ga["len"].cpu().numpy()[q0:q1], mine_l) and np.array_equal(ga["status"].cpu().numpy()[q0:q1], st)
-                  and np.array_equal(ga["cost"].cpu().numpy()[q0:q1], out["cost"].cpu().numpy()))
+        Gm = main_run["group"]
+        m0 = rank * Gm * Qloc                      # step 0 of this rank's block in the gathered arrays
+        ok = bool(np.array_equal(ga["len"].cpu().numpy()[m0:m0 + Qloc], mine_l) and np.array_equal(ga["status"].cpu().numpy()[m0:m0 + Qloc], st)
+                  and np.array_equal(ga["cost"].cpu().numpy()[m0:m0 + Qloc], out["cost"].cpu().numpy()))
         for q in range(Qloc):
             if st[q] == 0:
-                ok = ok and np.array_equal(cells[off[q0 + q]:off[q0 + q] + mine_l[q]], mine_p[q, :mine_l[q]])
+                ok = ok and np.array_equal(cells[off[m0 + q]:off[m0 + q] + mine_l[q]], mine_p[q, :mine_l[q]])
+        # every step of the group carries the same queries here: the last step of this rank's block must equal the first
+        ml = m0 + (Gm - 1) * Qloc
+        ok = ok and np.array_equal(ga["len"].cpu().numpy()[ml:ml + Qloc], mine_l)
+        for q in range(0, Qloc, 17):
+            if st[q] == 0:
+                ok = ok and np.array_equal(cells[off[ml + q]:off[ml + q] + mine_l[q]], mine_p[q, :mine_l[q]])
         # paths of ANOTHER rank's block: replan a sample of its queries here (query i is the same on any rank) and compare
         checked_other = 0
         if world > 1:
@@ -261,20 +271,22 @@ def main():
             ctx.synchronize()
             op, ol, ost = oo["path"].cpu().numpy(), oo["len"].cpu().numpy(), oo["status"].cpu().numpy()
             gl, gs = ga["len"].cpu().numpy(), ga["status"].cpu().numpy()
+            n0 = r2_ * Gm * Qloc                    # step 0 of that rank's block
             for q in range(ns):
-                ok = ok and gs[o0 + q] == ost[q] and gl[o0 + q] == ol[q]
+                ok = ok and gs[n0 + q] == ost[q] and gl[n0 + q] == ol[q]
                 if ost[q] == 0:
-                    ok = ok and np.array_equal(cells[off[o0 + q]:off[o0 + q] + ol[q]], op[q, :ol[q]])
+                    ok = ok and np.array_equal(cells[off[n0 + q]:off[n0 + q] + ol[q]], op[q, :ol[q]])
             checked_other = ns
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32)
         if dist is not None:
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         assert int(okt.item()) == 1, "gather of result paths is inconsistent"
         gather_info = {"entry_point": "sc_allgather_paths (pack kernel -> one ncclAllGather over RCCL -> unpack kernel)",
-                       "bytes_received_per_rank_per_step": ctx.allgather_last_bytes(),
+                       "exchanges": "one per library call (all steps of the call)",
+                       "bytes_received_per_rank_per_step": ctx.allgather_last_bytes() // Gm,
                        "fixed_stride_bytes_per_rank_per_step": Qtot * (args.lmax + 3) * 4,
-                       "cells_per_rank_capacity": cap_cells, "truncated": int(ga["truncated"][0]),
-                       "paths_checked": "own block, cell for cell" + (f"; {checked_other} queries of rank {(rank + 1) % world}'s block replanned here and compared" if world > 1 else ""),
+                       "cells_per_rank_capacity_per_step": cap_cells, "truncated": int(ga["truncated"][0]),
+                       "paths_checked": "own block (first step cell for cell, last step sampled)" + (f"; {checked_other} queries of rank {(rank + 1) % world}'s block replanned here and compared" if world > 1 else ""),
                        "consistent_on_all_ranks": True}
 
     result = None
