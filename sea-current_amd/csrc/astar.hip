@@ -1038,9 +1038,11 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     }
     const size_t per_slot = gcells * gsz + bwords * 4 + (size_t)NBUCKET * cap * 4;
     size_t slots = ctx->astar_slot_budget / per_slot;
-    // two wavefronts per query when the batch leaves room for them (a single call's time is its longest search)
-    const bool dual = !full_g && (size_t)Q <= (size_t)astar_resident_dual(ctx) && (size_t)Q <= slots;
-    const size_t resident = dual ? (size_t)Q : (size_t)astar_resident_waves(ctx);
+    // Two wavefronts per query (astar_kernel_dual) for every batch: it wins on one call's time (its longest search is
+    // shorter) and on the saturated rate (fewer instructions per expansion); SC_ASTAR_DUAL=0 selects the one-wavefront kernel.
+    const size_t rdual = (size_t)astar_resident_dual(ctx);
+    const bool dual = !full_g && rdual > 0;
+    const size_t resident = dual ? rdual : (size_t)astar_resident_waves(ctx);
     if (slots > resident) slots = resident;
     if (slots > (size_t)Q) slots = Q;
     if (slots < 1) slots = 1;
