@@ -45,9 +45,10 @@
 // enqueued behind the first, with 16x the ring space per query (a handful of wavefronts; it returns
 // at once when the list is empty).
 //
-// Two kernels share astar_query: astar_kernel (one wavefront per query: the saturated rate, bound by instruction
-// issue) for batches larger than the chip holds, astar_kernel_dual (two wavefronts per query, see astar_query) for
-// batches of up to ~2000 queries, where the time of a call is the time of its longest search.
+// Two kernels share astar_query: astar_kernel_dual (two wavefronts per query, see astar_query) runs every batch -- it is
+// faster for one call (the longest search is shorter) and at saturation (fewer instructions per expansion);
+// astar_kernel (one wavefront per query, the design described above) runs sc_astar_gfield, the overflow retry pass and
+// SC_ASTAR_DUAL=0.
 #include "sc_internal.h"
 #include <stdlib.h>
 
@@ -280,8 +281,8 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 #define STAMP(i) do { } while (0)
 #endif
 
-// One query in scratch slot `slot`: by one wavefront (DUAL = false), or by two (DUAL = true, astar_kernel_dual: batches
-// small enough to give every query two resident wavefronts).  A search is bound by what ONE wavefront can issue per
+// One query in scratch slot `slot`: by one wavefront (DUAL = false), or by two (DUAL = true, astar_kernel_dual).
+// A search is bound by what ONE wavefront can issue per
 // frontier step, so the second wavefront takes the part of a wide step that the next step does not wait for:
 //   wavefront 0 pops, closes (the atomic OR), and queues only the SAME-f successors -- at most two moves per node are
 //     same-f (the diagonal towards the goal and the straight move along the major axis), known from the geometry without
