@@ -303,7 +303,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
     __shared__ uint8_t dup_tbl[DUAL ? 1024 : 1];   // DUAL: who pops cell (x + 32 y) mod 1024 in this step
-    __shared__ uint32_t hq_xy[DUAL ? HQ : 1], hq_m[DUAL ? HQ : 1];   // hand-over ring: node, moves | legal moves << 8
+    __shared__ uint2 hq_rec[DUAL ? HQ : 1];   // hand-over ring: (node y << 16 | x, moves | legal moves << 8)
     __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
     const int lane = threadIdx.x & 63;
@@ -413,8 +413,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             }
             if (rec) {
                 const int r = (hq_tl + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))) & (HQ - 1);
-                hq_xy[r] = (uint32_t)hy << 16 | (uint32_t)hx;
-                hq_m[r] = hm | hp << 8;
+                hq_rec[r] = make_uint2((uint32_t)hy << 16 | (uint32_t)hx, hm | hp << 8);
             }
             hq_tl += cnt;
             wave_lds_sync();
@@ -477,7 +476,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             const int n = min(tl - hd, 64);
             const bool valid = lane < n;
             const int r = (hd + lane) & (HQ - 1);
-            const uint32_t xy = valid ? hq_xy[r] : 0u, m = valid ? hq_m[r] : 0u;
+            const uint2 rec = valid ? hq_rec[r] : make_uint2(0u, 0u);
+            const uint32_t xy = rec.x, m = rec.y;
             const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_fcur, __ATOMIC_RELAXED, SCOPE));
             hd += n;
             wave_lds_sync();
