@@ -88,6 +88,7 @@ struct astar_args {
     int32_t* ovf_count;  // ... and how many
     int32_t* ovf_sticky; // set on any overflow, cleared by the host when it next synchronises
     int nstat;           // Q of the batch (stride of the statistics arrays)
+    int lazy;            // two-wavefront kernel: more queries than slots -- wavefront 1 waits for fuller batches
     int tw, bw;          // tiles per row of the g array / of the closed bitmap
     size_t gcells, bwords;
 };
@@ -304,7 +305,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
     __shared__ uint8_t dup_tbl[DUAL ? 1024 : 1];   // DUAL: who pops cell (x + 32 y) mod 1024 in this step
     __shared__ uint2 hq_rec[DUAL ? HQ : 1];   // hand-over ring: (node y << 16 | x, moves | legal moves << 8)
-    __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
+    __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found, hq_flush;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
     const int lane = threadIdx.x & 63;
     const int wv = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -346,7 +347,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     int fcur = octile(sx, sy, gx, gy);
     if (wv == 0 && lane == 0) {
         qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
-        hq_tail = 0; hq_head = 0; hq_clean = 0; hq_stop = 0; hq_ovf = 0; hq_fcur = fcur; hq_found = 0;
+        hq_tail = 0; hq_head = 0; hq_clean = 0; hq_stop = 0; hq_ovf = 0; hq_fcur = fcur; hq_found = 0; hq_flush = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bitmap is clear before the first atomic OR
     wave_lds_sync();
@@ -468,6 +469,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
                 ++b_idle;
 #endif
+                continue;
+            }
+            if (a.lazy && tl - hd < 48 && !stop &&
+                __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_flush, __ATOMIC_RELAXED, SCOPE)) != tl) {
+                // a busy chip: wait for a fuller batch (fuller rounds of 64 successors) unless wavefront 0 is waiting for us
+                __builtin_amdgcn_s_sleep(4);
                 continue;
             }
 #ifdef ASTAR_STAMPS
@@ -809,6 +816,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         if (DUAL) {
             // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them
             STAMP(0);
+            if (a.lazy && lane == 0) __hip_atomic_store(&hq_flush, hq_tl, __ATOMIC_RELAXED, SCOPE);
             while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl) {
                 __builtin_amdgcn_s_sleep(1);
 #ifdef ASTAR_STAMPS
@@ -1066,7 +1074,7 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     hipLaunchKernelGGL(astar_prep_kernel, dim3(1), dim3(1024), 0, ctx->stream, start, goal, Q, W, H, sorted ? order : (int32_t*)nullptr, ctr);
     astar_args a{(const uint8_t*)ctx->moves.p, d2, W, H, rmin, start, goal, qgrid, sorted ? order : nullptr, nullptr, Q, Lmax, path, len,
                  cost, status, ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
-                 ovf_list, ctr + 1, ctr + 4, Q, tw, bw, gcells, bwords};
+                 ovf_list, ctr + 1, ctr + 4, Q, (dual && (size_t)Q > slots) ? 1 : 0, tw, bw, gcells, bwords};
     if (full_g) hipLaunchKernelGGL(astar_kernel<uint32_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
     else if (dual) hipLaunchKernelGGL(astar_kernel_dual<uint8_t>, dim3((unsigned)slots), dim3(128), 0, ctx->stream, a);
     else hipLaunchKernelGGL(astar_kernel<uint8_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
