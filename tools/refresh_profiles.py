@@ -52,7 +52,7 @@ log = open(os.path.join(src, "astar_FETCH_SIZE.log")).read()
 m = re.search(r"x4096: ([\d.]+) ms, (\d+) expansions / (\d+) popped / (\d+) steps each -> ([\d.]+) G", log)
 ms, ex, pop, steps, gexp = float(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
 copies = 4096
-astar = {"workload": "4096 copies of one salt20 query (tools/astar_saturation.py salt20 4096) in one launch: the chip is full and there is no tail",
+astar = {"workload": "4096 copies of one salt20 query (tools/astar_saturation.py salt20 4096) in one launch of astar_kernel_dual (2048 resident slots of two wavefronts: two rounds, no tail); per_step = per frontier step of wavefront 0, both wavefronts' instructions counted",
          "expansions_per_query": ex, "popped_per_query": pop, "steps_per_query": steps, "launch_ms_under_profiler": ms,
          "G_expansions_per_s_under_profiler": gexp}
 
