@@ -57,7 +57,7 @@ typedef enum {
     SC_K_EDT_COLBITS = 0, /* occupancy bytes -> transposed per-band column bit words */
     SC_K_EDT_BAND = 1,    /* per 32-row band: vertical distances + exact row envelope -> d2 */
     SC_K_MOVES = 2,       /* d2 + clearance -> legal-move byte per cell */
-    SC_K_ASTAR = 3,       /* batched A*: one wavefront per query */
+    SC_K_ASTAR = 3,       /* batched A*: two wavefronts per query (prep + search + retry launches) */
     SC_K_TOPPRA = 4,      /* batched TOPP-RA: computeParams + backward + forward sweep */
     SC_K_TOPPRA_SAMPLE = 5,
     SC_K_BEZIER = 6,      /* tangents + control points, curve evaluation */
