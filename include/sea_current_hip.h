@@ -287,9 +287,11 @@ int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, const float
  *   out  len_all / cost_all / status_all [Q_total], offsets_all int64 [Q_total + 1] (cells in front of each query;
  *        only paths with status SC_Q_OK count), cells_all [cells_capacity] the paths back to back (may be NULL),
  *        path_all [Q_total][Lmax] the fixed-stride parity layout (may be NULL), *truncated != 0 if some rank's paths
- *        exceeded cap_cells (cells beyond it read -1; gather again with a larger cap_cells).
+ *        exceeded cap_cells (bit 0: cells beyond it read -1; gather again with a larger cap_cells) or cells_all is too
+ *        small (bit 1).
  *   cap_cells: cells a rank's message can carry (the same on all ranks).  One ncclAllGather of
- *        (2 + 3 ceil(Q_total / world) + cap_cells) int32 per rank. */
+ *        sc_gather_msg_words(Q_total, world, cap_cells) = 2 + 3 ceil(Q_total / world) + cap_cells (rounded up to even)
+ *        int32 per rank. */
 void sc_rank_range(int Q, int world, int rank, int* q0, int* q1);
 int sc_comm_unique_id(void* id128);
 int sc_comm_init(sc_ctx* ctx, const void* id128, int nranks, int rank);
@@ -300,6 +302,21 @@ int sc_allgather_paths(sc_ctx* ctx, const int32_t* path, const int32_t* len, con
                        int64_t* offsets_all, int32_t* cells_all, int64_t cells_capacity, int32_t* path_all, int32_t* truncated);
 /* bytes every rank received in the last sc_allgather_paths on this context */
 int sc_allgather_last_bytes(sc_ctx* ctx, int64_t* bytes);
+/* The two halves of sc_allgather_paths on their own, for a caller whose transport is not RCCL (the reference's is ZMQ,
+ * examples/zmq_test.cpp:18-22) and for tests that play several ranks on one GPU.  Device pointers, enqueued, no host
+ * synchronisation, no communicator needed.
+ *   sc_gather_msg_words : int32 words of one rank's message for (Q_total, world, cap_cells); 0 for bad arguments.
+ *   sc_gather_pack      : rank `rank` of `world` packs its Q_local results into msg [sc_gather_msg_words] (Q_local must be
+ *                         what sc_rank_range gives that rank; 0 is allowed and the input pointers may then be NULL).
+ *   sc_gather_unpack    : msgs = the `world` messages back to back in rank order -> the outputs of sc_allgather_paths.
+ *   *truncated: bit 0 = some rank's paths exceeded cap_cells (cells beyond it read -1), bit 1 = cells_all is smaller
+ *   than offsets_all[Q_total] (cells beyond cells_capacity are not written).  sc_allgather_paths sets the same bits. */
+int64_t sc_gather_msg_words(int Q_total, int world, int cap_cells);
+int sc_gather_pack(sc_ctx* ctx, const int32_t* path, const int32_t* len, const int32_t* cost, const int32_t* status, int Q_local,
+                   int Q_total, int world, int rank, int Lmax, int cap_cells, int32_t* msg);
+int sc_gather_unpack(sc_ctx* ctx, const int32_t* msgs, int world, int Q_total, int Lmax, int cap_cells, int32_t* len_all,
+                     int32_t* cost_all, int32_t* status_all, int64_t* offsets_all, int32_t* cells_all, int64_t cells_capacity,
+                     int32_t* path_all, int32_t* truncated);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,7 @@ extern "C" int sc_comm_init(sc_ctx* ctx, const void* id128, int nranks, int rank
     if (!a) { snprintf(ctx->err, sizeof(ctx->err), "librccl.so could not be loaded"); return SC_ERR_NO_DEVICE; }
     SC_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->comm && ctx->comm_owned) (void)a->comm_destroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_ranks = 0; ctx->comm_rank = 0;   // nothing dangles if the init below fails
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t c = nullptr;
@@ -165,16 +166,18 @@ gather_pack_kernel(const int32_t* __restrict__ path, const int32_t* __restrict__
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= qmax) return;
     int32_t* meta = msg + MSG_META;
+    if (q == 0 && lane == 0) {   // header, also of a rank that owns no query at all (Q_total < world)
+        const long long total = off[Ql];
+        msg[MSG_USED] = (int32_t)(total < cap_cells ? total : cap_cells);
+        msg[MSG_TRUNC] = total > cap_cells ? 1 : 0;
+    }
     if (q >= Ql) {   // padding of a rank with one query fewer
         if (lane == 0) { meta[q] = 0; meta[qmax + q] = -1; meta[2 * qmax + q] = SC_Q_NO_PATH; }
         return;
     }
     const int ln = len[q], st = status[q];
-    const long long o = off[q], total = off[Ql];
-    if (lane == 0) {
-        meta[q] = ln; meta[qmax + q] = cost[q]; meta[2 * qmax + q] = st;
-        if (q == 0) { msg[MSG_USED] = (int32_t)(total < cap_cells ? total : cap_cells); msg[MSG_TRUNC] = total > cap_cells ? 1 : 0; }
-    }
+    const long long o = off[q];
+    if (lane == 0) { meta[q] = ln; meta[qmax + q] = cost[q]; meta[2 * qmax + q] = st; }
     const int n = st == SC_Q_OK ? min(max(ln, 0), Lmax) : 0;
     int32_t* dst = msg + MSG_META + 3 * (size_t)qmax;
     const int32_t* src = path + (size_t)q * Lmax;
@@ -194,6 +197,7 @@ gather_unpack_kernel(const int32_t* __restrict__ msgs, int stride, int qmax, int
     const int q0 = r * base + min(r, rem);
     const int32_t* m = msgs + (size_t)r * stride;
     if (q == q0 && lane == 0 && m[MSG_TRUNC]) atomicOr(flag, 1);
+    if (q == 0 && lane == 0 && cells_all && off_all[Q] > cells_capacity) atomicOr(flag, 2);   // the caller's compact array is too small
     const int n = status_all[q] == SC_Q_OK ? min(max(len_all[q], 0), Lmax) : 0;
     const long long o_local = off_all[q] - off_all[q0];          // cells of this rank in front of query q
     const long long o = off_all[q];
@@ -206,14 +210,105 @@ gather_unpack_kernel(const int32_t* __restrict__ msgs, int stride, int qmax, int
     }
 }
 
+// Words of one rank's message.  The cell area starts after an even number of words and the whole message is an even
+// number of words, so messages laid back to back keep 8-byte alignment for whatever follows them.
+static size_t gather_stride(int Q_total, int world, int cap_cells) {
+    const size_t qmax = (size_t)((Q_total + world - 1) / world);
+    size_t w = (size_t)MSG_META + 3 * qmax + (size_t)cap_cells;
+    return w + (w & 1);
+}
+
+extern "C" int64_t sc_gather_msg_words(int Q_total, int world, int cap_cells) {
+    if (Q_total <= 0 || world < 1 || cap_cells <= 0) return 0;
+    return (int64_t)gather_stride(Q_total, world, cap_cells);
+}
+
+// scratch of the gather: [ local offsets int64 [qmax + 1] | this rank's message | every rank's messages ]
+static int gather_scratch(sc_ctx* ctx, int Q_total, int world, int cap_cells, bool with_msgs, int64_t** off_local, int32_t** msg, int32_t** msgs) {
+    const size_t qmax = (size_t)((Q_total + world - 1) / world);
+    const size_t stride = gather_stride(Q_total, world, cap_cells);
+    const size_t off_bytes = (qmax + 2) / 2 * 2 * sizeof(int64_t);
+    int r = sc_scratch_reserve(ctx, &ctx->gather_msg, off_bytes + stride * (size_t)(with_msgs ? world + 1 : 1) * sizeof(int32_t));
+    if (r != SC_OK) return r;
+    *off_local = (int64_t*)ctx->gather_msg.p;                   // 8-byte data first: aligned whatever the sizes
+    *msg = (int32_t*)((char*)ctx->gather_msg.p + off_bytes);
+    if (msgs) *msgs = *msg + stride;
+    return SC_OK;
+}
+
+static int gather_pack_launch(sc_ctx* ctx, const int32_t* path, const int32_t* len, const int32_t* cost, const int32_t* status, int Q_local,
+                              int qmax, int Lmax, int cap_cells, int64_t* off_local, int32_t* msg) {
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, len, status, (const int32_t*)nullptr, 0, qmax, 1, Q_local > 0 ? Q_local : 0,
+                       Lmax, off_local, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(gather_pack_kernel, dim3((qmax + 3) / 4), dim3(256), 0, ctx->stream, path, len, cost, status, Q_local, qmax, Lmax, cap_cells,
+                       (const int64_t*)off_local, msg);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+static int gather_unpack_launch(sc_ctx* ctx, const int32_t* msgs, size_t stride, int qmax, int world, int Q_total, int Lmax, int cap_cells,
+                                int32_t* len_all, int32_t* cost_all, int32_t* status_all, int64_t* offsets_all, int32_t* cells_all,
+                                int64_t cells_capacity, int32_t* path_all, int32_t* truncated) {
+    SC_HIP(ctx, hipMemsetAsync(truncated, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)nullptr, (const int32_t*)nullptr, msgs,
+                       (int)stride, qmax, world, Q_total, Lmax, offsets_all, len_all, cost_all, status_all);
+    hipLaunchKernelGGL(gather_unpack_kernel, dim3((Q_total + 3) / 4), dim3(256), 0, ctx->stream, msgs, (int)stride, qmax, world, Q_total,
+                       Lmax, cap_cells, (const int64_t*)offsets_all, (const int32_t*)len_all, (const int32_t*)status_all, cells_all,
+                       (long long)cells_capacity, path_all, truncated);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+static bool gather_sizes_ok(int Q_total, int world, int Lmax, int cap_cells) {
+    // message offsets are 32-bit words of an int-sized stride
+    return Q_total > 0 && world >= 1 && Lmax > 0 && cap_cells > 0 && gather_stride(Q_total, world, cap_cells) <= (size_t)INT32_MAX;
+}
+
+// The two halves of sc_allgather_paths on their own (device pointers, enqueued, no host synchronisation): what a caller
+// with a transport of its own -- or a test that plays several ranks on one GPU -- puts around the exchange.
+extern "C" int sc_gather_pack(sc_ctx* ctx, const int32_t* path, const int32_t* len, const int32_t* cost, const int32_t* status, int Q_local,
+                              int Q_total, int world, int rank, int Lmax, int cap_cells, int32_t* msg) {
+    if (!ctx || !msg || Q_local < 0 || rank < 0 || rank >= world || !gather_sizes_ok(Q_total, world, Lmax, cap_cells) ||
+        (Q_local > 0 && (!path || !len || !cost || !status)))
+        return SC_ERR_INVALID;
+    int q0, q1;
+    sc_rank_range(Q_total, world, rank, &q0, &q1);
+    if (q1 - q0 != Q_local) { snprintf(ctx->err, sizeof(ctx->err), "sc_gather_pack: rank %d of %d owns %d of %d queries, not %d", rank, world, q1 - q0, Q_total, Q_local); return SC_ERR_INVALID; }
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t* off_local; int32_t* own;
+    int r = gather_scratch(ctx, Q_total, world, cap_cells, false, &off_local, &own, nullptr);
+    if (r != SC_OK) return r;
+    const int qmax = (Q_total + world - 1) / world;
+    int tk = sc_time_begin(ctx, SC_K_GATHER);
+    r = gather_pack_launch(ctx, path, len, cost, status, Q_local, qmax, Lmax, cap_cells, off_local, msg);
+    sc_time_end(ctx, tk);
+    return r;
+}
+
+extern "C" int sc_gather_unpack(sc_ctx* ctx, const int32_t* msgs, int world, int Q_total, int Lmax, int cap_cells, int32_t* len_all,
+                                int32_t* cost_all, int32_t* status_all, int64_t* offsets_all, int32_t* cells_all, int64_t cells_capacity,
+                                int32_t* path_all, int32_t* truncated) {
+    if (!ctx || !msgs || !len_all || !cost_all || !status_all || !offsets_all || !truncated || !gather_sizes_ok(Q_total, world, Lmax, cap_cells) ||
+        (cells_all && cells_capacity <= 0))
+        return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const int qmax = (Q_total + world - 1) / world;
+    int tk = sc_time_begin(ctx, SC_K_GATHER);
+    int r = gather_unpack_launch(ctx, msgs, gather_stride(Q_total, world, cap_cells), qmax, world, Q_total, Lmax, cap_cells, len_all, cost_all,
+                                 status_all, offsets_all, cells_all, cells_capacity, path_all, truncated);
+    sc_time_end(ctx, tk);
+    return r;
+}
+
 extern "C" int sc_allgather_paths(sc_ctx* ctx, const int32_t* path, const int32_t* len, const int32_t* cost, const int32_t* status,
                                   int Q_local, int Q_total, int Lmax, int cap_cells, int32_t* len_all, int32_t* cost_all, int32_t* status_all,
                                   int64_t* offsets_all, int32_t* cells_all, int64_t cells_capacity, int32_t* path_all, int32_t* truncated) {
-    if (!ctx || !path || !len || !cost || !status || !len_all || !cost_all || !status_all || !offsets_all || !truncated || Q_local < 0 ||
-        Q_total <= 0 || Lmax <= 0 || cap_cells <= 0 || (cells_all && cells_capacity <= 0))
+    if (!ctx || !len_all || !cost_all || !status_all || !offsets_all || !truncated || Q_local < 0 ||
+        (Q_local > 0 && (!path || !len || !cost || !status)) || (cells_all && cells_capacity <= 0))
         return SC_ERR_INVALID;
     if (!ctx->comm) { snprintf(ctx->err, sizeof(ctx->err), "sc_allgather_paths: no communicator (sc_comm_init / sc_comm_adopt)"); return SC_ERR_INVALID; }
     const int world = ctx->comm_ranks, rank = ctx->comm_rank;
+    if (!gather_sizes_ok(Q_total, world, Lmax, cap_cells)) return SC_ERR_INVALID;
     int q0, q1;
     sc_rank_range(Q_total, world, rank, &q0, &q1);
     if (q1 - q0 != Q_local) { snprintf(ctx->err, sizeof(ctx->err), "sc_allgather_paths: rank %d of %d owns %d of %d queries, not %d", rank, world, q1 - q0, Q_total, Q_local); return SC_ERR_INVALID; }
@@ -221,27 +316,19 @@ extern "C" int sc_allgather_paths(sc_ctx* ctx, const int32_t* path, const int32_
     if (!a) return SC_ERR_NO_DEVICE;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const int qmax = (Q_total + world - 1) / world;
-    const size_t stride = (size_t)MSG_META + 3 * (size_t)qmax + (size_t)cap_cells;
-    int r = sc_scratch_reserve(ctx, &ctx->gather_msg, (stride * (size_t)(world + 1)) * sizeof(int32_t) + ((size_t)qmax + 1) * sizeof(int64_t));
+    const size_t stride = gather_stride(Q_total, world, cap_cells);
+    int64_t* off_local; int32_t *msg, *msgs;
+    int r = gather_scratch(ctx, Q_total, world, cap_cells, true, &off_local, &msg, &msgs);
     if (r != SC_OK) return r;
-    int32_t* msg = (int32_t*)ctx->gather_msg.p;                 // this rank's message
-    int32_t* msgs = msg + stride;                               // every rank's
-    int64_t* off_local = (int64_t*)(msgs + stride * world);
     int tk = sc_time_begin(ctx, SC_K_GATHER);
-    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, len, status, (const int32_t*)nullptr, 0, qmax, 1, Q_local > 0 ? Q_local : 0,
-                       Lmax, off_local, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
-    hipLaunchKernelGGL(gather_pack_kernel, dim3((qmax + 3) / 4), dim3(256), 0, ctx->stream, path, len, cost, status, Q_local, qmax, Lmax, cap_cells,
-                       (const int64_t*)off_local, msg);
+    r = gather_pack_launch(ctx, path, len, cost, status, Q_local, qmax, Lmax, cap_cells, off_local, msg);
+    if (r != SC_OK) { sc_time_end(ctx, tk); return r; }
     const ncclResult_t nr = a->all_gather(msg, msgs, stride, ncclInt32, (ncclComm_t)ctx->comm, ctx->stream);
-    if (nr != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", nr);
-    SC_HIP(ctx, hipMemsetAsync(truncated, 0, sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)msgs,
-                       (int)stride, qmax, world, Q_total, Lmax, offsets_all, len_all, cost_all, status_all);
-    hipLaunchKernelGGL(gather_unpack_kernel, dim3((Q_total + 3) / 4), dim3(256), 0, ctx->stream, (const int32_t*)msgs, (int)stride, qmax, world, Q_total,
-                       Lmax, cap_cells, (const int64_t*)offsets_all, (const int32_t*)len_all, (const int32_t*)status_all, cells_all,
-                       (long long)cells_capacity, path_all, truncated);
+    if (nr != ncclSuccess) { sc_time_end(ctx, tk); return rccl_fail(ctx, "ncclAllGather", nr); }
+    r = gather_unpack_launch(ctx, msgs, stride, qmax, world, Q_total, Lmax, cap_cells, len_all, cost_all, status_all, offsets_all, cells_all,
+                             cells_capacity, path_all, truncated);
     sc_time_end(ctx, tk);
-    SC_HIP(ctx, hipGetLastError());
+    if (r != SC_OK) return r;
     ctx->gather_bytes = (int64_t)stride * sizeof(int32_t) * world;
     return SC_OK;
 }

@@ -89,6 +89,9 @@ _SIGNATURES = {
     "sc_comm_destroy": (_i, [_vp]),
     "sc_allgather_paths": (_i, [_vp] * 5 + [_i, _i, _i, _i] + [_vp] * 5 + [C.c_int64, _vp, _vp]),
     "sc_allgather_last_bytes": (_i, [_vp, _i64p]),
+    "sc_gather_msg_words": (C.c_int64, [_i, _i, _i]),
+    "sc_gather_pack": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
+    "sc_gather_unpack": (_i, [_vp, _vp, _i, _i, _i, _i] + [_vp] * 5 + [C.c_int64, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -257,6 +260,38 @@ class Context:
                                             cap_cells, _ptr(bufs["len"]), _ptr(bufs["cost"]), _ptr(bufs["status"]), _ptr(bufs["offsets"]),
                                             _ptr(bufs["cells"]), bufs["cells"].numel(), _ptr(bufs.get("path")), _ptr(bufs["truncated"])),
                  "sc_allgather_paths")
+        return bufs
+
+    def gather_pack(self, out, Q_total, world, rank, cap_cells, msg=None, Lmax=None):
+        """This rank's message of the gather (sc_gather_pack): int32 [sc_gather_msg_words].  `out` = the rank's astar_batch
+        dict (may hold zero queries)."""
+        import torch
+        Ql = int(out["len"].shape[0])
+        if Lmax is None:
+            Lmax = int(out["path"].shape[1])
+        words = int(self._l.sc_gather_msg_words(Q_total, world, cap_cells))
+        if msg is None:
+            msg = torch.empty(words, dtype=torch.int32, device=out["len"].device)
+        assert msg.numel() == words
+        nz = Ql > 0
+        self._ck(self._l.sc_gather_pack(self._h, _ptr(out["path"]) if nz else None, _ptr(out["len"]) if nz else None,
+                                        _ptr(out["cost"]) if nz else None, _ptr(out["status"]) if nz else None, Ql, Q_total, world, rank,
+                                        Lmax, cap_cells, _ptr(msg)), "sc_gather_pack")
+        return msg
+
+    def gather_unpack(self, msgs, world, Q_total, Lmax, cap_cells, want_path=False, cells_capacity=None):
+        """sc_gather_unpack: `msgs` = the world messages back to back in rank order -> the dict allgather_paths returns."""
+        import torch
+        dev = msgs.device
+        cc = world * cap_cells if cells_capacity is None else cells_capacity
+        bufs = dict(len=torch.empty(Q_total, dtype=torch.int32, device=dev), cost=torch.empty(Q_total, dtype=torch.int32, device=dev),
+                    status=torch.empty(Q_total, dtype=torch.int32, device=dev), offsets=torch.empty(Q_total + 1, dtype=torch.int64, device=dev),
+                    cells=torch.full((cc,), -7, dtype=torch.int32, device=dev), truncated=torch.zeros(1, dtype=torch.int32, device=dev))
+        if want_path:
+            bufs["path"] = torch.full((Q_total, Lmax), -7, dtype=torch.int32, device=dev)
+        self._ck(self._l.sc_gather_unpack(self._h, _ptr(msgs), world, Q_total, Lmax, cap_cells, _ptr(bufs["len"]), _ptr(bufs["cost"]),
+                                          _ptr(bufs["status"]), _ptr(bufs["offsets"]), _ptr(bufs["cells"]), cc, _ptr(bufs.get("path")),
+                                          _ptr(bufs["truncated"])), "sc_gather_unpack")
         return bufs
 
     def allgather_last_bytes(self):

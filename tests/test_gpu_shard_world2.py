@@ -1,7 +1,9 @@
 """The HIP compute path under more than one rank: two processes share the box's one GPU (a context each), every rank
-runs EDT + A* of ITS block of the query list through the C ABI, the blocks are gathered (gloo here: RCCL refuses two
-ranks on one device; the RCCL transport itself is covered at world size 1 by test_gpu_gather.py) and every rank must
-hold the whole batch, in query order, equal to the oracle's single-process result."""
+runs EDT + A* of ITS block of the query list through the C ABI and packs its results with sc_gather_pack (device); the
+messages travel between the processes with a gloo all_gather (RCCL refuses two ranks on one device; the RCCL transport
+itself is covered at world size 1 by test_gpu_gather.py) and sc_gather_unpack on every rank must leave the whole batch, in
+query order, equal to the oracle's single-process result -- the same pack / unpack kernels sc_allgather_paths runs around
+its ncclAllGather."""
 import os
 import socket
 
@@ -35,13 +37,17 @@ def _worker(rank, world, port, Q, ret):
         s, g = synth.queries(d2.cpu().numpy() >= 1, Q, seed=7)
         Lmax = 1024
 
-        def plan_fn(s_loc, g_loc):
-            out = ctx.astar_batch(d2, s_loc.cuda(), g_loc.cuda(), Lmax=Lmax)
-            torch.cuda.synchronize()
-            return {k: v.cpu() for k, v in out.items()}
-
-        out = shard.plan_sharded(plan_fn, torch.from_numpy(s), torch.from_numpy(g), world, rank, dist, Lmax=Lmax, compact=True)
-        ret[rank] = {k: v.numpy().copy() for k, v in out.items()}
+        q0, q1 = shard.rank_range(Q, world, rank)
+        out = ctx.astar_batch(d2, torch.from_numpy(s[q0:q1]).cuda(), torch.from_numpy(g[q0:q1]).cuda(), Lmax=Lmax)
+        cap = 16384
+        msg = ctx.gather_pack(out, Q, world, rank, cap)
+        torch.cuda.synchronize()
+        words = msg.numel()
+        all_msgs = torch.empty(world * words, dtype=torch.int32)
+        dist.all_gather_into_tensor(all_msgs, msg.cpu())
+        got = ctx.gather_unpack(all_msgs.cuda(), world, Q, Lmax, cap)
+        torch.cuda.synchronize()
+        ret[rank] = {k: v.cpu().numpy().copy() for k, v in got.items()}
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -61,6 +67,7 @@ def test_two_ranks_hip_compute(oracle, Q):
     ref = oracle.astar_batch(d2, s, g, Lmax=1024)
     for r in range(world):
         o = ret[r]
+        assert int(o["truncated"][0]) == 0
         for k in ("len", "cost", "status"):
             assert np.array_equal(o[k], ref[k]), (r, k)
         for q in range(Q):
