@@ -695,6 +695,442 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     }
 }
 
+// ---- edt_updown_kernel: per (band, column), rows to the nearest obstacle in the bands above / below -----------
+// ud[b][x] = up | dn << 16: up = rows from the band's FIRST row up to the nearest obstacle of an earlier band, dn = rows
+// from its LAST row down to the nearest obstacle of a later band (EDT_G_INF: none).  With it a band kernel needs two
+// words per column -- its own bits and this -- whatever the map looks like, instead of walking neighbouring bands' words
+// until it finds an obstacle (up to 18 loads per column pair and round, and a data-dependent loop on open maps).
+// Block = 64 columns x 16 band groups: every thread scans its PER <= 16 consecutive bands (words stay in registers), the
+// groups exchange their highest / lowest obstacle row through LDS, and each thread finishes its own bands.
+template <int PER>
+__global__ void __launch_bounds__(1024)
+edt_updown_kernel(const uint32_t* __restrict__ colbits, int W, int nb, uint32_t* __restrict__ ud) {
+    __shared__ int2 s_lf[16][64];                   // (last, first) obstacle row of every band group, per column
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + tx, g = blockIdx.y;
+    const int b0 = ty * PER;                        // PER = ceil(nb / 16) rounded up to a power of two
+    const uint32_t* cb = colbits + (size_t)g * nb * W;
+    uint32_t wv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) wv[k] = (b0 + k < nb && x < W) ? cb[(size_t)(b0 + k) * W + x] : 0u;
+    int last = -1, first = 0x7FFFFFFF;              // global rows of the group's last / first obstacle
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (wv[k]) {
+            const int base = (b0 + k) * 32;
+            if (first == 0x7FFFFFFF) first = base + __ffs((int)wv[k]) - 1;
+            last = base + 31 - __clz((int)wv[k]);
+        }
+    s_lf[ty][tx] = make_int2(last, first);
+    __syncthreads();
+    int run_up = -1, run_dn = 0x7FFFFFFF;
+    for (int t = 0; t < ty; ++t) run_up = max(run_up, s_lf[t][tx].x);
+    for (int t = ty + 1; t < 16; ++t) run_dn = min(run_dn, s_lf[t][tx].y);
+    if (x >= W) return;
+    uint32_t upv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int base = (b0 + k) * 32;
+        upv[k] = run_up >= 0 ? (uint32_t)min(base - run_up, EDT_G_INF) : (uint32_t)EDT_G_INF;
+        if (wv[k]) run_up = base + 31 - __clz((int)wv[k]);
+    }
+#pragma unroll
+    for (int k = PER - 1; k >= 0; --k) {
+        const int b = b0 + k, base = b * 32;
+        const uint32_t dn = run_dn != 0x7FFFFFFF ? (uint32_t)min(run_dn - (base + 31), EDT_G_INF) : (uint32_t)EDT_G_INF;
+        if (wv[k]) run_dn = base + __ffs((int)wv[k]) - 1;
+        if (b < nb) ud[((size_t)g * nb + b) * W + x] = upv[k] | (dn << 16);
+    }
+}
+
+static void launch_updown(sc_ctx* ctx, const uint32_t* colbits, int W, int nb, int batch, uint32_t* ud) {
+    const dim3 grid((W + 63) / 64, batch), block(1024);
+    const int per = (nb + 15) / 16;
+    if (per <= 1) hipLaunchKernelGGL(edt_updown_kernel<1>, grid, block, 0, ctx->stream, colbits, W, nb, ud);
+    else if (per <= 2) hipLaunchKernelGGL(edt_updown_kernel<2>, grid, block, 0, ctx->stream, colbits, W, nb, ud);
+    else if (per <= 4) hipLaunchKernelGGL(edt_updown_kernel<4>, grid, block, 0, ctx->stream, colbits, W, nb, ud);
+    else if (per <= 8) hipLaunchKernelGGL(edt_updown_kernel<8>, grid, block, 0, ctx->stream, colbits, W, nb, ud);
+    else hipLaunchKernelGGL(edt_updown_kernel<16>, grid, block, 0, ctx->stream, colbits, W, nb, ud);   // nb <= 256 (H <= 8192)
+}
+
+// ---- edt_band_wide_kernel: rows of 1025 .. 4096 pixels, whole rows in registers -------------------------
+// A row is TILES stretches of 1024 pixels; lane l keeps pixels 1024 t + 16 l .. + 15 of every stretch t in 8 packed registers
+// (the W <= 1024 layout, TILES times), so a cascade step is the same register work per pixel and the two end pixels of a
+// lane come from the adjacent lanes by one wave rotation per stretch and side -- lane 0 / 63 take the rotated register of
+// the neighbouring stretch instead.  No windows, no halo columns, no flags and no second launch: a 4096-pixel row costs four
+// times a 1024-pixel one.  A workgroup owns 16 rows (half a band of column words: 64 KiB of distance bytes at W = 4096,
+// two workgroups per CU); each wave transposes through the LDS row it has already pulled into registers.
+//
+// The step itself is two packed instructions per register instead of three: T = P + (2 it - 1), then
+// P = min3(P, T[left], T[right]) with v_pk_minimum3_f16 -- on bit patterns 0 .. 0x7C00 (non-negative f16, denormals
+// included) the f16 order is the integer order (tools/microbench/min3_mb.hip checks the instruction on 32 M triples).
+// To stay below the NaN patterns the distance bytes are clamped at 177 (packed values below 177^2 = 31329 are exact) and
+// the cascade stops after 175 steps (T <= 31329 + 349 < 0x7C00); rows that need more (very sparse grids) are redone at
+// the end by a 32-bit outward scan over exact distances, in the LDS the distance bytes no longer need.
+#define EDT_W_GCAP 177u
+#define EDT_W_ITMAX 175
+__device__ __forceinline__ uint32_t pk_min3_f16bits(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_wrap(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
+}
+// lane l <- lane l-1, lane 0 <- lane 63 / lane l <- lane l+1, lane 63 <- lane 0
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C /*wave_ror:1*/, 0xF, 0xF, true);   // every lane is written: no old value
+}
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /*wave_rol:1*/, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, b) + __builtin_bit_cast(us2_t, c)));
+}
+
+// One workgroup per CU, 16 wavefronts, persistent over a strided set of row groups (16 rows each), and NO workgroup
+// barrier in the loop.  The distance bytes of a group live in one of two LDS slots.  Wavefronts 0-7 are PRODUCERS: each
+// owns an eighth of the columns and turns their column words into the distance bytes of the next group (vertical pass,
+// pure VALU + LDS) as soon as the slot's previous group has been consumed.  Rows of a finished group are claimed one at a
+// time (compare-and-swap on an LDS counter) by every wavefront that has nothing to produce: the eight CONSUMERS always,
+// the producers in between.  Three monotonic LDS counters per slot carry the protocol:
+//     p1_cnt   producer parts written, ever      group n (use k = n / 2 of its slot) is readable at 8 (k + 1)
+//     row_next rows claimed, ever                claims of use k are RB k .. RB (k + 1) - 1
+//     row_done rows finished, ever               the slot may be refilled for use k + 1 at RB (k + 1)
+// Vertical pass, cascade and stores of one CU then overlap by construction and no wavefront waits for the slowest row of
+// a group -- as two phases of one set of wavefronts, separated by a barrier, all CUs computed and then all CUs stored
+// (71 us for four 4096^2 grids, of which 18 were the vertical pass alone).  Every wait is bounded (EDT_W_SPIN_LIMIT).
+#define EDT_W_SPIN_LIMIT (1 << 22)
+// Ordering between the wavefronts of the workgroup goes through LDS only, and the LDS operations of a wave execute in issue
+// order: what is needed is that the compiler keeps the order and that earlier LDS results have arrived -- NOT a
+// workgroup-scope fence, whose s_waitcnt vmcnt(0) would make every row wait for its own HBM stores to be acknowledged.
+#define EDT_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int TILES, bool FULL>
+__global__ void __launch_bounds__(1024, 4)
+edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __restrict__ updown, int W, int H, int nb, int nsb, int ngroups,
+                     int32_t* __restrict__ d2, uint16_t* __restrict__ rowbuf) {
+    static_assert(TILES >= 2 && TILES <= 4, "rows of 1025 .. 4096 pixels");
+    constexpr int RB = 16;                          // rows per group
+    constexpr int NP = 8;                           // producer wavefronts
+    constexpr int WP = 1024 * TILES;
+    constexpr uint32_t GC2 = EDT_W_GCAP | (EDT_W_GCAP << 16);
+    constexpr uint32_t EDGE = 0x7BFF7BFFu;          // beyond the row ends: above every value, below the f16 NaN patterns
+    constexpr uint32_t UDCAP = 0x70007000u;         // "no obstacle" for up / dn: still a non-negative finite f16 pattern after + 32
+    extern __shared__ uint32_t smem[];              // [2][RB][WP] distance bytes, clamped at EDT_W_GCAP
+    __shared__ uint32_t p1_cnt[2], row_next[2], row_done[2];
+    // XCD-aware order (see edt_band_g8_kernel): an XCD works through a contiguous run of (grid, row group) pairs
+    const unsigned nwg = gridDim.x, per = nwg >> 3;
+    const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    // groups vid, vid + nwg, vid + 2 nwg, ...: neighbouring groups cost about the same (on block-type maps up to 10x the
+    // mean), so a contiguous run per workgroup leaves the launch waiting for its dearest run; a strided set samples the maps
+    const int G = (int)vid < ngroups ? (ngroups - 1 - (int)vid) / (int)nwg + 1 : 0;
+    const bool producer = threadIdx.x < NP * 64;
+    const int tid = threadIdx.x & (NP * 64 - 1);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 2) { p1_cnt[threadIdx.x] = 0; row_next[threadIdx.x] = 0; row_done[threadIdx.x] = 0; }
+    __syncthreads();
+
+    // ---- vertical pass of group n (producers): two adjacent columns per thread and round -> RB rows of 2 distance bytes.
+    // All words of the thread's rounds are requested first (one memory round trip), then the recurrences run.
+    auto produce = [&](int n) {
+        const int s = (int)vid + n * (int)nwg;
+        const int sb = s % nsb, g = s / nsb;
+        const int y0 = sb * RB;
+        const int b = y0 >> 5, r0 = y0 & 31;        // band of column words, first bit of this row group in them
+        uint8_t* g8 = reinterpret_cast<uint8_t*>(smem) + (size_t)(n & 1) * RB * WP;
+        const uint32_t* cw = colbits + ((size_t)g * nb + b) * W;
+        const uint32_t* ub = updown + ((size_t)g * nb + b) * W;
+        uint32_t wq[TILES][2], uq[TILES][2];
+        if (FULL || !(W & 1)) {
+#pragma unroll
+            for (int r = 0; r < TILES; ++r) {
+                const int x = 2 * (tid + NP * 64 * r);
+                uint2 a = make_uint2(0u, 0u), u = make_uint2(UDCAP, UDCAP);
+                if (FULL || x < W) { a = *reinterpret_cast<const uint2*>(cw + x); u = *reinterpret_cast<const uint2*>(ub + x); }
+                wq[r][0] = a.x; wq[r][1] = a.y; uq[r][0] = u.x; uq[r][1] = u.y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < TILES; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int x = 2 * (tid + NP * 64 * r) + c;
+                    wq[r][c] = x < W ? cw[x] : 0u;
+                    uq[r][c] = x < W ? ub[x] : UDCAP;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < TILES; ++r) {
+            const int q = tid + NP * 64 * r;
+            uint32_t nw[2], up[2], dn[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t w = wq[r][c];
+                const uint32_t u = pk_min(uq[r][c], UDCAP);
+                up[c] = u & 0xFFFFu; dn[c] = u >> 16;           // from the band's first / last row
+                // rows of the band's own word outside this group decide first; then measured from the group's first / last row
+                const uint32_t wlow = r0 ? (w & ((1u << r0) - 1u)) : 0u;
+                const uint32_t whigh = r0 + RB < 32 ? (w >> (r0 + RB)) : 0u;
+                up[c] = wlow ? (uint32_t)(r0 - (31 - __clz((int)wlow))) : up[c] + (uint32_t)r0;
+                dn[c] = whigh ? (uint32_t)__ffs((int)whigh) : dn[c] + (uint32_t)(32 - (r0 + RB));
+                nw[c] = ~(w >> r0);
+            }
+            // top-down: gu_i = free_i ? gu_{i-1} + 1 : 0 as one packed multiply-add; bottom-up gd likewise; g = min(gu, gd, cap)
+            // is one min3 on the f16 order (all values are below 0x7C00)
+            const uint32_t nwA = (nw[0] & 0xFFFFu) | (nw[1] << 16);
+            uint32_t GU[RB], FR[RB];
+            uint32_t gu = (up[0] - 1u) | ((up[1] - 1u) << 16);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                FR[i] = (nwA >> i) & 0x00010001u;
+                gu = pk_mad_u16(gu, FR[i], FR[i]);
+                GU[i] = gu;
+            }
+            // Two rows at a time: the thread's 2 x 2 distance bytes go to its partner lane (lane ^ 1) and each lane of the pair
+            // stores ONE dword -- the even lane the four columns of the upper row, the odd lane those of the lower row --
+            // instead of two 2-byte pieces each (LDS store instructions cost the same whatever their width).
+            uint32_t gd = (dn[0] - 1u) | ((dn[1] - 1u) << 16);
+            const uint32_t psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+            uint8_t* dst = g8 + (size_t)(lane & 1) * WP + 2 * (q & ~1);
+#pragma unroll
+            for (int i = RB - 2; i >= 0; i -= 2) {
+                gd = pk_mad_u16(gd, FR[i + 1], FR[i + 1]);
+                const uint32_t g1 = pk_min3_f16bits(GU[i + 1], gd, GC2);
+                gd = pk_mad_u16(gd, FR[i], FR[i]);
+                const uint32_t g0 = pk_min3_f16bits(GU[i], gd, GC2);
+                const uint32_t own = __builtin_amdgcn_perm(g1, g0, 0x06040200u);   // bytes: row i (col 0, col 1), row i + 1 (col 0, col 1)
+                const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, true);
+                *reinterpret_cast<uint32_t*>(dst + (size_t)i * WP) = __builtin_amdgcn_perm(oth, own, psel);
+            }
+        }
+    };
+
+    int hint = 4;   // cascade steps the wave's previous row needed (rows claimed in a row are often neighbours)
+    // ---- row i of group n: cascade, transposition, stores ----
+    auto consume_row = [&](int n, int i) {
+        const int s = (int)vid + n * (int)nwg;
+        const int sb = s % nsb, g = s / nsb;
+        const int y0 = sb * RB;
+        if (y0 + i >= H) return;                    // rows past the grid's last one (the group still counts RB claims)
+        const int b = y0 >> 5, r0 = y0 & 31;
+        const uint32_t* cb = colbits + (size_t)g * nb * W;
+        uint32_t* gbuf = smem + (size_t)(n & 1) * (RB * WP / 4);
+        const uint8_t* g8 = reinterpret_cast<const uint8_t*>(gbuf);
+        int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
+        uint32_t* tr = gbuf + (size_t)i * (WP / 4);   // transposition buffer: the row's own bytes, dead once in registers
+        uint32_t P[TILES][8];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const uint4 v = *reinterpret_cast<const uint4*>(g8 + (size_t)i * WP + 1024 * t + 16 * lane);
+            const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t sel = 0x0C000C00u | (uint32_t)(j % 4) | ((uint32_t)(4 + j % 4) << 16);
+                const uint32_t tt = __builtin_amdgcn_perm(dw[(j + 8) / 4], dw[j / 4], sel);
+                P[t][j] = pk_mul_lo(tt, tt);      // <= 177^2: pixels past the row end carry 177 ("no obstacle")
+            }
+        }
+        auto cascade_step = [&](int it) {
+            const uint32_t c = (uint32_t)(2 * it - 1) * 0x00010001u;
+            uint32_t Tl[TILES], Tf[TILES], lo[TILES], hi[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) { Tl[t] = pk_add_wrap(P[t][7], c); Tf[t] = pk_add_wrap(P[t][0], c); }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) { lo[t] = wave_ror1(Tl[t]); hi[t] = wave_rol1(Tf[t]); }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const uint32_t below = lane == 0 ? (t ? lo[t ? t - 1 : 0] : EDGE) : lo[t];
+                const uint32_t above = lane == 63 ? (t < TILES - 1 ? hi[t < TILES - 1 ? t + 1 : t] : EDGE) : hi[t];
+                const uint32_t L0 = __builtin_amdgcn_alignbit(Tl[t], below, 16);   // T of the left neighbours of pixels (0, 8)
+                const uint32_t RL = __builtin_amdgcn_alignbit(above, Tf[t], 16);   // T of the right neighbours of pixels (7, 15)
+                uint32_t T[8];
+                T[0] = Tf[t]; T[7] = Tl[t];
+#pragma unroll
+                for (int j = 1; j < 7; ++j) T[j] = pk_add_wrap(P[t][j], c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) P[t][j] = pk_min3_f16bits(P[t][j], j ? T[j - 1] : L0, j < 7 ? T[j + 1] : RL);
+            }
+        };
+        // The convergence test costs about half a step.  It starts one step before the count the wave's previous row needed
+        // (at most at step 8: the previous row may have been another map's), runs every step for a while and then at steps
+        // an eighth apart.  When to test only affects how many surplus steps run, never the result.
+        bool saturated = false;
+        int it = 1, next_chk = max(2, min(hint - 1, 8));
+        for (; it <= EDT_W_ITMAX; ++it) {
+            cascade_step(it);
+            const bool last = it == EDT_W_ITMAX;
+            if (!last && it < next_chk) continue;
+            next_chk = it + 1 + (it >= 12 ? (it >> 3) : 0);
+            uint32_t m = 0;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                uint32_t mt = P[t][0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) mt = pk_max(mt, P[t][j]);
+                mt = max(mt & 0xFFFFu, mt >> 16);
+                if (!FULL) {
+                    const int nv = W - (1024 * t + 16 * lane);   // pixels of this lane inside the row
+                    if (nv <= 0) mt = 0;
+                    else if (nv < 16) {
+                        mt = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (j < nv) mt = max(mt, P[t][j] & 0xFFFFu);
+                            if (j + 8 < nv) mt = max(mt, P[t][j] >> 16);
+                        }
+                    }
+                }
+                m = max(m, mt);
+            }
+            const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
+            if (__ballot(m > thr) == 0) break;
+            if (last) { saturated = true; break; }
+        }
+        hint = it;
+        if (saturated) {
+            // ---- the packed cascade cannot settle this row (a very sparse grid): exact distances as u16 in the wavefront's
+            // row of global scratch, then per pixel an outward scan that stops once k^2 reaches the best value.  Correct
+            // for any input, not fast.
+            uint16_t* row = rowbuf + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * (size_t)W;
+            for (int x = lane; x < W; x += 64) row[x] = (uint16_t)edt_gdist_global(cb, W, nb, b, x, r0 + i);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int x = lane; x < W; x += 64) {
+                const int g0 = __hip_atomic_load(row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int best = g0 * g0;
+                for (int k = 1; k < W && k * k < best; ++k) {
+                    const int xl = x - k, xr = x + k;
+                    const int gl = xl >= 0 ? (int)__hip_atomic_load(row + xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : EDT_G_INF;
+                    const int gr = xr < W ? (int)__hip_atomic_load(row + xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : EDT_G_INF;
+                    const int gm = min(gl, gr);
+                    best = min(best, gm * gm + k * k);
+                }
+                out[x] = best >= EDT_F_INF ? INT32_MAX : best;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scratch row is rewritten by this wave's next failed row
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            // Transposition of one stretch through LDS.  The registers are first re-paired so that a dword holds two ADJACENT
+            // pixels (pixel 2m | pixel 2m + 1 << 16): the lane's 16 pixels are then 32 contiguous bytes (two 16-byte writes,
+            // swapped in every other group of four lanes so that eight consecutive lanes cover all banks once) and the four
+            // pixels of a 16-byte global store are ONE 8-byte read -- half the LDS read traffic of reading packed registers
+            // back as 16 bytes and keeping one half of every dword.
+            uint32_t R[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                R[m] = __builtin_amdgcn_perm(P[t][2 * m + 1], P[t][2 * m], 0x05040100u);       // pixels 2m, 2m + 1
+                R[m + 4] = __builtin_amdgcn_perm(P[t][2 * m + 1], P[t][2 * m], 0x07060302u);   // pixels 8 + 2m, 9 + 2m
+            }
+            uint32_t* wb = tr + 8 * lane;
+            const int sw = (lane >> 2) & 1;
+            *reinterpret_cast<uint4*>(wb + 4 * sw) = make_uint4(R[0], R[1], R[2], R[3]);
+            *reinterpret_cast<uint4*>(wb + 4 * (1 - sw)) = make_uint4(R[4], R[5], R[6], R[7]);
+            wave_lds_sync();
+            // piece 64 k + lane = pixels 4 (64 k + lane) ..: owner lane 16 k + lane / 4, quarter lane % 4 of its 32 bytes
+            const uint32_t* rb = tr + 8 * (lane >> 2) + 4 * (((lane >> 1) & 1) ^ ((lane >> 4) & 1)) + 2 * (lane & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 qv = *reinterpret_cast<const uint2*>(rb + 128 * k);
+                const int4 v = make_int4((int)(qv.x & 0xFFFFu), (int)(qv.x >> 16), (int)(qv.y & 0xFFFFu), (int)(qv.y >> 16));
+                const int xg = 1024 * t + 4 * (64 * k + lane);
+                if (FULL || xg + 3 < W) {
+                    if (FULL || (((uintptr_t)(out + xg)) & 15) == 0) EDT_STORE4(out + xg, v);
+                    else { out[xg] = v.x; out[xg + 1] = v.y; out[xg + 2] = v.z; out[xg + 3] = v.w; }
+                } else {
+                    if (xg < W) out[xg] = v.x;
+                    if (xg + 1 < W) out[xg + 1] = v.y;
+                    if (xg + 2 < W) out[xg + 2] = v.z;
+                }
+            }
+            wave_lds_sync();
+        }
+    };
+
+    // ---- the scheduler of one wavefront: produce when the slot is free (producers), else claim a row, else wait ----
+    volatile uint32_t* v_p1 = p1_cnt;
+    volatile uint32_t* v_next = row_next;
+    volatile uint32_t* v_done = row_done;
+    int pn = 0, cn = 0, spin = 0;
+    while (cn < G || (producer && pn < G)) {
+        bool did = false;
+        if (producer && pn < G) {
+            const int slot = pn & 1, k = pn >> 1;
+            if (k == 0 || v_done[slot] >= (uint32_t)(RB * k)) {       // every row of the slot's previous group has been consumed
+                EDT_LDS_ORDER();
+                produce(pn);
+                EDT_LDS_ORDER();
+                if (lane == 0) atomicAdd(&p1_cnt[slot], 1u);
+                ++pn; did = true;
+            }
+        }
+        if (!did && cn < G) {
+            const int slot = cn & 1, k = cn >> 1;
+            if (v_p1[slot] >= (uint32_t)(NP * (k + 1))) {               // all eight producer parts of group cn are written
+                int i = -1;
+                if (lane == 0) {
+                    uint32_t v = v_next[slot];
+                    while (v < (uint32_t)(RB * (k + 1))) {
+                        const uint32_t old = atomicCAS(&row_next[slot], v, v + 1u);
+                        if (old == v) { i = (int)(v - (uint32_t)(RB * k)); break; }
+                        v = old;
+                    }
+                }
+                i = __builtin_amdgcn_readfirstlane(i);
+                if (i < 0) ++cn;                                        // all rows of this group are claimed: on to the next
+                else {
+                    EDT_LDS_ORDER();
+                    consume_row(cn, i);
+                    EDT_LDS_ORDER();
+                    if (lane == 0) atomicAdd(&row_done[slot], 1u);
+                }
+                did = true;
+            }
+        }
+        if (did) spin = 0;
+        else {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spin > EDT_W_SPIN_LIMIT) break;                       // never expected; a bounded wait cannot hang the GPU
+        }
+    }
+}
+
+template <int TILES, bool FULL>
+static int launch_band_wide(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+    const int nsb = (H + 15) / 16;
+    const int ngroups = nsb * batch;
+    const size_t lds = (size_t)2 * 16 * 1024 * TILES;
+    {
+        int r_ = sc_allow_big_lds(ctx, reinterpret_cast<const void*>(edt_band_wide_kernel<TILES, FULL>), (int)lds);
+        if (r_ != SC_OK) return r_;
+    }
+    if (ctx->cu_count <= 0) {
+        hipDeviceProp_t prop;
+        ctx->cu_count = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    // one workgroup (16 wavefronts) per CU, each with a strided set of row groups
+    const int nwg = min(ngroups, ctx->cu_count);
+    int tk = ctx->edt_open_token;   // opened in front of the updown launch (-1: timing off)
+    ctx->edt_open_token = -1;
+    {   // one row of u16 per wavefront for the rows the packed cascade gives up on
+        int r_ = sc_scratch_reserve(ctx, &ctx->edt_rowbuf, (size_t)nwg * 16 * W * sizeof(uint16_t));
+        if (r_ != SC_OK) return r_;
+    }
+    hipLaunchKernelGGL((edt_band_wide_kernel<TILES, FULL>), dim3((unsigned)nwg), dim3(1024), lds, ctx->stream, colbits,
+                       (const uint32_t*)ctx->updown.p, W, H, nb, nsb, ngroups, d2, (uint16_t*)ctx->edt_rowbuf.p);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+template <int TILES>
+static int launch_band_wide_t(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+    return W == 1024 * TILES ? launch_band_wide<TILES, true>(ctx, colbits, W, H, nb, batch, d2)
+                             : launch_band_wide<TILES, false>(ctx, colbits, W, H, nb, batch, d2);
+}
+
 template <int PPL, bool FULL>
 static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     constexpr int WP = 64 * PPL;
@@ -797,8 +1233,23 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
 #endif
     if (W <= 512) return launch_band_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 1024) return launch_band_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
-    // wider rows: 1024-column windows through the fast kernel first, then the whole-row kernel for the grids (if any)
-    // in which some row did not settle within the window's halo
+#ifndef EDT_NO_WIDE
+    // rows of up to 4096 pixels: whole rows in registers, 16 rows per workgroup
+    if ((size_t)((H + 15) / 16) * batch <= 0x7FFFFFFFu) {
+        r = sc_scratch_reserve(ctx, &ctx->updown, (size_t)batch * nb * W * sizeof(uint32_t));
+        if (r != SC_OK) return r;
+        colbits = (uint32_t*)ctx->colbits.p;
+        // timing: the look-up table of the band kernel counts as band time (the colbits bracket ends here)
+        if (ctx->edt_chain_token >= 0) ctx->edt_open_token = sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND);
+        ctx->edt_chain_token = -1;
+        launch_updown(ctx, colbits, W, nb, batch, (uint32_t*)ctx->updown.p);
+        if (W <= 2048) return launch_band_wide_t<2>(ctx, colbits, W, H, nb, batch, d2);
+        if (W <= 3072) return launch_band_wide_t<3>(ctx, colbits, W, H, nb, batch, d2);
+        if (W <= 4096) return launch_band_wide_t<4>(ctx, colbits, W, H, nb, batch, d2);
+    }
+#endif
+    // wider rows still: 1024-column windows through the fast kernel first, then the whole-row kernel for the grids (if
+    // any) in which some row did not settle within the window's halo
     const int32_t* flags = nullptr;
 #ifndef EDT_NO_G8
     {

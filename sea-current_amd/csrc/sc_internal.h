@@ -30,6 +30,8 @@ struct sc_ctx {
     int64_t t_n[SC_K_COUNT] = {0};
     // scratch (grow-only)
     sc_scratch colbits;     // EDT: uint32 [batch][nb][W]
+    sc_scratch updown;      // EDT, rows wider than 1024: uint32 [batch][nb][W], rows to the nearest obstacle in the bands above / below
+    sc_scratch edt_rowbuf;  // EDT, rows wider than 1024: uint16 [workgroups][16][W], exact distances of a row redone in 32 bits
     sc_scratch edt_flags;   // EDT, rows wider than 1024: int32 [2][batch][bands], != 0 where a windowed pass gave a band up
     sc_scratch moves;       // A*: uint8 [H][W]
     sc_scratch gslots;      // A*: uint32 [S][g cells] (4 x 4-cell tiles)
@@ -47,11 +49,13 @@ struct sc_ctx {
     size_t astar_slot_budget = (size_t)96 << 30;  // bytes of g + bitmap + ring scratch allowed (SC_ASTAR_SLOT_GB); 4096^2: 96 GiB = 1966 slots measured best (48: -34 %, 160: -17 %)
     int last_Q = 0;
     int edt_chain_token = -1;       // timing: colbits' end event doubles as band's start event
+    int edt_open_token = -1;        // timing: band bracket already opened (wide rows: in front of the updown launch)
     void* comm = nullptr;           // ncclComm_t of sc_allgather_paths
     bool comm_owned = false;
     int comm_ranks = 0, comm_rank = 0;
     int64_t gather_bytes = 0;       // bytes every rank received in the last gather
     std::set<const void*> big_lds_done;   // kernels whose dynamic-LDS limit this context has raised on its device
+    int cu_count = 0;               // compute units of the device (0: not asked yet)
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
     int astar_dual = -1;   // queries the two-wavefront A* kernel keeps resident (-1: not asked yet, 0: off)
 };

@@ -118,15 +118,16 @@ def test_edt_nearest_matches_oracle(ctx, oracle):
         assert np.array_equal(nb[k], oracle.edt_nearest(ob[k].cpu().numpy(), d2b[k].cpu().numpy()))
 
 
-@pytest.mark.parametrize("W,H", [(1025, 40), (1984, 33), (2049, 70), (3000, 64)])
-def test_edt_wide_rows_windows_and_fallback(ctx, oracle, W, H):
-    """Rows wider than 1024 run in 1024-column windows; a grid with a row that does not settle within the halo is redone
-    by the whole-row kernel.  One batch mixes both kinds (the flag is per grid), plus an empty grid."""
+@pytest.mark.parametrize("W,H", [(1025, 40), (1984, 33), (2049, 70), (3000, 64), (3073, 17), (4095, 31), (4096, 50), (5000, 40)])
+def test_edt_wide_rows(ctx, oracle, W, H):
+    """Rows of 1025 .. 4096 pixels run whole in registers (edt_band_wide_kernel: 16-row groups, producer / consumer
+    wavefronts); rows its packed cascade cannot settle (distances beyond 175 columns) are redone in 32 bits inside the same
+    launch; wider rows still go through 1024-column windows.  One batch mixes dense, sparse, seam and empty grids."""
     import torch
     rng = np.random.default_rng(W)
     dense = (rng.random((H, W)) < 0.2).astype(np.uint8)
-    sparse = (rng.random((H, W)) < 2e-4).astype(np.uint8)             # distances far beyond the 32-column halo
-    edge = np.zeros((H, W), np.uint8); edge[:, 959:962] = 1; edge[H // 2, W - 1] = 1   # obstacles on a window seam
+    sparse = (rng.random((H, W)) < 2e-4).astype(np.uint8)             # distances of hundreds of columns
+    edge = np.zeros((H, W), np.uint8); edge[:, 959:962] = 1; edge[H // 2, W - 1] = 1   # obstacles at a 1024-column seam
     empty = np.zeros((H, W), np.uint8)
     occ = np.stack([dense, sparse, edge, empty, dense[::-1].copy()])
     d2 = ctx.edt(torch.from_numpy(occ).cuda())
@@ -136,10 +137,49 @@ def test_edt_wide_rows_windows_and_fallback(ctx, oracle, W, H):
         assert np.array_equal(got[b], oracle.edt(occ[b])), b
 
 
+@pytest.mark.parametrize("W", [2048, 3100, 4096])
+def test_edt_wide_rows_packed_range_boundary(ctx, oracle, W):
+    """Free stretches whose half-width straddles what the packed cascade can represent (176 columns, distance bytes clamped
+    at 177): walls 2 d + 1 columns apart leave d free columns either side of the middle, with d from 168 to 184, in rows
+    far from any other obstacle; plus vertical distances around the clamp."""
+    import torch
+    H = 420
+    occ = np.zeros((H, W), np.uint8)
+    x = 3
+    for d in range(168, 185):
+        if x + 2 * d + 2 >= W:
+            break
+        occ[:, x] = 1
+        x += 2 * d + 1
+    occ[:, min(x, W - 1)] = 1
+    occ2 = np.zeros((H, W), np.uint8)
+    occ2[0, :] = 1; occ2[H - 1, ::3] = 1          # vertical distances up to 209 in the middle rows
+    d2 = ctx.edt(torch.from_numpy(np.stack([occ, occ2])).cuda())
+    torch.cuda.synchronize()
+    got = d2.cpu().numpy()
+    assert np.array_equal(got[0], oracle.edt(occ))
+    assert np.array_equal(got[1], oracle.edt(occ2))
+
+
+def test_edt_wide_many_groups_per_workgroup(ctx, oracle):
+    """More row groups than workgroups (the persistent kernel's slots are reused many times): 3 grids of 2048 x 1500 are
+    282 groups on at most 256 workgroups -- and 36 grids of 1040 x 200 give every workgroup several -- against the oracle."""
+    import torch
+    from sea_current_amd import synth
+    occ = np.stack([synth.block_grid(2048, 1500, 0.2, seed=70 + i) for i in range(3)])
+    got = ctx.edt(torch.from_numpy(occ).cuda()).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.edt(occ[i])), i
+    occ = np.stack([synth.salt_grid(1040, 200, 0.02 * (1 + i % 5), seed=90 + i) for i in range(36)])
+    got = ctx.edt(torch.from_numpy(occ).cuda()).cpu().numpy()
+    for i in range(36):
+        assert np.array_equal(got[i], oracle.edt(occ[i])), i
+
+
 def test_two_contexts_two_threads_big_lds_kernels(oracle):
     """Two contexts driven from two host threads at once through the kernels that need more than 64 KiB of dynamic LDS
-    (4096-wide rows: the windowed kernel and, on a map with wide open areas, the whole-row kernel behind it): the raised
-    LDS limit is per context, so neither depends on the other having run first."""
+    (4096-wide rows: the whole-row kernel with its 128 KiB of distance bytes): the raised LDS limit is per context, so
+    neither depends on the other having run first."""
     import threading
     import torch
     import sea_current_amd as sc
