@@ -11,10 +11,12 @@ the result paths over RCCL when N > 1].  Inputs (grid, queries) are resident in 
 Rank 0 prints ONE JSON line.  Weak scaling: every rank plans `--queries` (default 1024) queries;
 value = (N * queries * K) / max-over-ranks time of the K steps.  Query i is the same on any rank count.
 
-Consecutive steps are independent batches.  No entry point of the library blocks the host any more, so the K steps
-are simply enqueued, round-robin, on `--depth` contexts (a context = one HIP stream + its scratch); a stream runs its
-steps in order, so a slot's buffers are never written by two steps at once.  One host thread, one synchronisation at
-the end.  `--depth 1` = strictly sequential steps on one stream (also reported in the default run as `value_depth1`).
+Consecutive steps are independent batches: step k has its OWN grid (seed SEED_GRID + k) and its own query block
+(queries k * Qtot .. of the generator, drawn on that grid).  No entry point of the library blocks the host, so the K
+steps are simply enqueued, `--group` consecutive steps per library call, calls round-robin on `--depth` contexts (a
+context = one HIP stream + its scratch); one host thread, one synchronisation at the end.  The K-step region is timed
+`--repeats` times (barrier + synchronise on both sides of each, max over ranks): `value` is the MEDIAN repeat, minimum
+and maximum beside it.  `value_depth1` = one call per step on one stream (what ONE call of 1024 queries gets).
 
 Also measured (outside the timed steps, reported in the same line):
   roofline     -- the EDT kernels on a batch of 64 grids (one 1024^2 grid is 5.2 MB: launch-bound
@@ -75,6 +77,7 @@ def main():
                          "0 = the largest divisor of --steps that is <= 32 (20 steps: one call of 20; 64 steps: 32 per call, "
                          "alternating between the contexts), so that exactly --steps steps are timed.  Measured: 20 steps as "
                          "2 x 10 on two contexts 478 k plans/s, as one call 559 k; 64 steps as 4 x 16, 2 x 32 or 1 x 64: 544-557 k")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step region is timed (value = median)")
     ap.add_argument("--lmax", type=int, default=4096)
     ap.add_argument("--edt-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,19 +146,21 @@ def main():
     # on the headline map); a rank whose paths do not fit is flagged in `gather.truncated`
     cap_cells = Qloc * args.lmax // 4
 
-    def run_map(family, steps, warmup, depth, with_toppra=False, group=1):
+    def run_map(family, steps, warmup, depth, with_toppra=False, group=1, repeats=1):
         """Timed region for one obstacle family: `steps` x (EDT + batched A* [+ gather] [+ TOPP-RA]) on `depth` contexts,
         `group` consecutive steps per library call (every step still has its own grid buffer, distance map and results)."""
         G = max(1, min(group, steps))
-        occ_h = make_grid(family, W, H)
-        occ = torch.from_numpy(np.stack([occ_h] * G)).to(dev)          # the grids of G steps (inputs; same content)
+        # step k of a call: its own grid and its own queries (query block k of the generator, drawn from that grid's largest
+        # free component -- needs each grid's traversable mask once, on the host)
+        occ_hs = [make_grid(family, W, H, seed=synth.SEED_GRID + k) for k in range(G)]
+        occ = torch.from_numpy(np.stack(occ_hs)).to(dev)
         d2s = [torch.empty((G, H, W), dtype=torch.int32, device=dev) for _ in range(depth)]
         ctx.edt(occ, out=d2s[0])
         ctx.synchronize()
-        # queries are drawn from the largest free component (needs the traversable mask once, on the host)
-        s_h, g_h = synth.queries(d2s[0][0].cpu().numpy() >= 1, q1 - q0, first=q0)
-        start = torch.from_numpy(np.tile(s_h, G)).to(dev)
-        goal = torch.from_numpy(np.tile(g_h, G)).to(dev)
+        sg = [synth.queries(d2s[0][k].cpu().numpy() >= 1, q1 - q0, first=k * Qtot + q0) for k in range(G)]
+        occ_h, s_h, g_h = occ_hs[0], sg[0][0], sg[0][1]
+        start = torch.from_numpy(np.concatenate([a for a, _ in sg])).to(dev)
+        goal = torch.from_numpy(np.concatenate([b for _, b in sg])).to(dev)
         qgrid = torch.from_numpy(np.repeat(np.arange(G, dtype=np.int32), Qloc)).to(dev)
         outs = [alloc_out(G) for _ in range(depth)]
         gath = [None] * depth
@@ -197,15 +202,21 @@ def main():
         keep.clear()
         ctx.set_timing(True)
         ctx.reset_timing()
-        t0 = time.perf_counter()
-        run_steps(steps)
-        t_enq = time.perf_counter() - t0
-        fence()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt_ = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-            dt = float(tt_.item())
+        dts, t_enq = [], 0.0
+        for _ in range(max(1, repeats)):
+            fence()
+            t0 = time.perf_counter()
+            run_steps(steps)
+            t_enq = time.perf_counter() - t0
+            fence()
+            dt_r = time.perf_counter() - t0
+            if dist is not None:
+                tt_ = torch.tensor([dt_r], dtype=torch.float64)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                dt_r = float(tt_.item())
+            dts.append(dt_r)
+            keep.clear()
+        dt = float(np.median(dts))
         kern = {}
         for name, kid in (("edt_colbits", sc.K_EDT_COLBITS), ("edt_band", sc.K_EDT_BAND), ("moves", sc.K_MOVES), ("astar", sc.K_ASTAR),
                           ("gather", sc.K_GATHER), ("toppra", sc.K_TOPPRA), ("toppra_sample", sc.K_TOPPRA_SAMPLE)):
@@ -213,12 +224,15 @@ def main():
             if n:
                 kern[name] = {"ms_per_launch_on_context0": ms / n, "launches": n}
         ctx.set_timing(False)
-        expansions = ctx.astar_last_expansions() // G
+        expansions = ctx.astar_last_expansions() // G      # mean over the steps of the last call on context 0
         out = view(outs[0], 0)
         st = out["status"].cpu().numpy()
         ln = out["len"].cpu().numpy()
         astar_ms = kern["astar"]["ms_per_launch_on_context0"]
+        lastk = G - 1
         res = dict(value=Qtot * steps / dt, ms_per_step=1e3 * dt / steps, host_enqueue_ms_per_step=1e3 * t_enq / steps, kernels=kern,
+                   repeats=len(dts), value_min=Qtot * steps / max(dts), value_max=Qtot * steps / min(dts),
+                   ms_per_region=[1e3 * d for d in dts],
                    astar={"expansions_per_step_rank0": expansions,
                           "launch_ms_on_context0": astar_ms,
                           "expansions_per_s_whole_job": expansions * world * steps / dt,
@@ -226,15 +240,22 @@ def main():
                           "found": int((st == 0).sum()), "no_path": int((st == 1).sum()), "ring_overflow": int((st == 4).sum()),
                           "mean_path_len": float(ln[st == 0].mean()) if (st == 0).any() else 0.0},
                    steps=steps, group=G,
-                   _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st, d2=d2s[0][0], gath=gath[0]))
+                   _host=dict(occ=occ_h, s=s_h, g=g_h, out=out, st=st, d2=d2s[0][0], gath=gath[0],
+                              lastk=lastk, occ_last=occ_hs[lastk], s_last=sg[lastk][0], g_last=sg[lastk][1], out_last=view(outs[0], lastk)))
         if with_toppra:
             res["toppra_ok"] = int((tp_last[0][0]["status"] == 0).sum())
         return res
 
     if args.group <= 0:
         args.group = max(g for g in range(1, 33) if args.steps % g == 0)
-    main_run = run_map(args.map, args.steps, args.warmup, depth_max, group=args.group)
-    seq_run = run_map(args.map, max(2, min(args.steps, 4)), 1, 1)                     # one call per step, one stream
+    assert (args.group * Qtot) % world == 0
+    main_run = run_map(args.map, args.steps, args.warmup, depth_max, group=args.group, repeats=args.repeats)
+    seq_run = run_map(args.map, max(2, min(args.steps, 4)), 1, 1, repeats=args.repeats)   # one call per step, one stream
+    qst = ctx.astar_debug_stats(Qloc)            # of seq_run's last call: expansions, popped entries, kilo-cycles, steps per query
+    kc = np.sort(qst[2].astype(np.float64))
+    per_query = {"kilocycles_p50": float(kc[len(kc) // 2]), "kilocycles_p99": float(kc[int(0.99 * (len(kc) - 1))]), "kilocycles_max": float(kc[-1]),
+                 "steps_p50": float(np.median(qst[3])), "steps_max": int(qst[3].max()), "expansions_max": int(qst[0].max()),
+                 "note": "one call of %d queries on one stream: in-kernel cycle count and dependent frontier steps of every search; the call ends with its longest search" % Qloc}
     others = {} if args.only_main_map else {f: run_map(f, args.steps, 1, depth_max, group=args.group) for f in FAMILIES if f != args.map}
     cfg2 = run_map(args.map, args.steps, 1, depth_max, with_toppra=True, group=args.group)
     occ_h, s_h, g_h, out, st = (main_run["_host"][k] for k in ("occ", "s", "g", "out", "st"))
@@ -254,12 +275,14 @@ def main():
         for q in range(Qloc):
             if st[q] == 0:
                 ok = ok and np.array_equal(cells[off[m0 + q]:off[m0 + q] + mine_l[q]], mine_p[q, :mine_l[q]])
-        # every step of the group carries the same queries here: the last step of this rank's block must equal the first
+        # the last step of this rank's block in the gathered arrays against that step's own results
+        ol_ = main_run["_host"]["out_last"]
+        l_l, l_s, l_p = ol_["len"].cpu().numpy(), ol_["status"].cpu().numpy(), ol_["path"].cpu().numpy()
         ml = m0 + (Gm - 1) * Qloc
-        ok = ok and np.array_equal(ga["len"].cpu().numpy()[ml:ml + Qloc], mine_l)
+        ok = ok and np.array_equal(ga["len"].cpu().numpy()[ml:ml + Qloc], l_l) and np.array_equal(ga["status"].cpu().numpy()[ml:ml + Qloc], l_s)
         for q in range(0, Qloc, 17):
-            if st[q] == 0:
-                ok = ok and np.array_equal(cells[off[ml + q]:off[ml + q] + mine_l[q]], mine_p[q, :mine_l[q]])
+            if l_s[q] == 0:
+                ok = ok and np.array_equal(cells[off[ml + q]:off[ml + q] + l_l[q]], l_p[q, :l_l[q]])
         # paths of ANOTHER rank's block: replan a sample of its queries here (query i is the same on any rank) and compare
         checked_other = 0
         if world > 1:
@@ -295,12 +318,18 @@ def main():
             "metric": "plans/sec (batched start-goal, 1024^2 grid)", "value": main_run["value"], "unit": "plans/s",
             "n_gpus": world, "steps": main_run["steps"], "warmup": args.warmup, "ms_per_step": main_run["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} random-obstacle grid ({args.map}), EDT + A*, {Qloc} batched queries per GPU"
+            "repeats": main_run["repeats"], "value_is": "median over the repeats of the timed K-step region",
+            "value_min": main_run["value_min"], "value_max": main_run["value_max"], "ms_per_region": main_run["ms_per_region"],
+            "config": {"workload": f"{W}x{H} random-obstacle grids ({args.map}, one grid and one query block per step), EDT + A*, {Qloc} batched "
+                                   f"queries per GPU and step, {main_run['group']} steps = {main_run['group'] * Qloc} queries per library call"
                                    + (", RCCL all-gather of paths" if use_gather else ""),
+                       "queries_per_launch": main_run["group"] * Qloc,
                        "grid": [W, H], "map": args.map, "queries_per_gpu": Qloc, "queries_total": Qtot, "lmax": args.lmax,
                        "parallelism": f"query-sharded x{world}", "contexts_in_flight": depth_max, "steps_per_call": main_run["group"],
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default")},
             "value_depth1": seq_run["value"], "ms_per_step_depth1": seq_run["ms_per_step"],
+            "value_depth1_is": f"one library call per step ({Qloc} queries per launch) on one stream: what BASELINE configs[1] literally describes",
+            "per_query_depth1": per_query,
             "host_enqueue_ms_per_step": main_run["host_enqueue_ms_per_step"],
             "kernels": main_run["kernels"], "astar": main_run["astar"],
             "other_maps": {f: {"value": r["value"], "ms_per_step": r["ms_per_step"],
@@ -346,7 +375,8 @@ def main():
             del grids, d2b
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "edt_colbits_kernel + edt_band_kernel (one EDT = both launches)",
+                    "kernel": ("edt_colbits_kernel + edt_band_g8_kernel (one EDT = both launches)" if Wl <= 1024 else
+                               "edt_colbits_kernel + edt_updown_kernel + edt_band_wide_kernel (one EDT = the three launches)"),
                     "workload": f"EDT of {B} x {Wl}x{Hl} {family} grids per launch pair",
                     "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": per_launch_ms,
                     "timing": f"HIP events around {iters} back-to-back EDTs on the launch stream",
@@ -386,6 +416,11 @@ def main():
         if (W, H) == (1024, 1024):   # BASELINE configs[3]'s grid: the same number of cells per launch pair
             result["roofline_4096"] = {fam: {kk: v[kk] for kk in keys + ("workload",)}
                                        for fam, v in ((f, edt_leg(f, 4096, 4096, max(1, B // 16))) for f in ("salt20", "blocks"))}
+            # the same kernels on a batch sized for HBM rather than for parity with the 1024^2 leg's byte count: 16 grids = 1.3 GB
+            # per launch (a persistent workgroup then runs 16 row groups instead of 4: pipeline fill and launch gaps amortised)
+            if B >= 64:
+                v16 = edt_leg("salt20", 4096, 4096, 16)
+                result["roofline_4096"]["salt20_16_grids"] = {kk: v16[kk] for kk in keys + ("workload",)}
 
         # ---- TOPP-RA leg (BASELINE configs[2]: 1k plans, 6-DOF, 200 waypoints): the kernels alone ----
         P, dof, N = 1024, 6, 200
@@ -444,7 +479,8 @@ def main():
                           "q8192 = the whole 8k-query frame on ONE GPU, q1024 = one GPU's share when 8 GPUs split the frame")
         result["replan_stream"] = replan
 
-    # ---- BASELINE configs[3], one GPU's share: 4096^2 grid, 8192 of the 64k queries (rank 0's block), N = 1 only ----
+    # ---- BASELINE configs[3], one GPU's share: 4096^2 grid, 8192 of the 64k queries (rank 0's block), N = 1 only, with the
+    # gather of the result paths in the loop: pack -> (ncclAllGather when a communicator exists: SC_BENCH_FORCE_DIST=1) -> unpack
     if rank == 0 and world == 1 and not args.only_main_map:
         W4 = H4 = 4096
         occ4 = torch.from_numpy(make_grid(args.map, W4, H4)).to(dev)
@@ -456,17 +492,58 @@ def main():
         L4 = 4 * args.lmax
         o4 = ctx.astar_batch(ctx.edt(occ4), s4d, g4d, Lmax=L4)       # warm-up (scratch allocation)
         torch.cuda.synchronize()
+        # message capacity from the measured path lengths (mean ~2-3 k cells of Lmax 16 k) with a quarter of headroom, not
+        # from Lmax: the gather then moves what the paths hold instead of Q * Lmax / 4 cells per rank
+        eff4 = torch.where(o4["status"] == 0, o4["len"], torch.zeros_like(o4["len"]))
+        cells4 = int(eff4.sum())
+        cap4 = int(1.25 * cells4) + 1024
+        words4 = int(sc.lib().sc_gather_msg_words(Q4, 1, cap4))
+        msg4 = torch.empty(words4, dtype=torch.int32, device=dev)
+        gb4 = None
+
+        def gather4(o):
+            if use_gather:
+                return ctx.allgather_paths(o, Q4, cap4, bufs=gb4)
+            ctx.gather_pack(o, Q4, 1, 0, cap4, msg=msg4)
+            return ctx.gather_unpack(msg4, 1, Q4, L4, cap4)
+        gb4 = gather4(o4) if use_gather else None
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        ctx.reset_timing()
         t0 = time.perf_counter()
         o4 = ctx.astar_batch(ctx.edt(occ4), s4d, g4d, Lmax=L4)
+        ga4 = gather4(o4)
         torch.cuda.synchronize()
         dt4 = time.perf_counter() - t0
+        ms_g4, n_g4 = ctx.get_timing(sc.K_GATHER)
+        ms_a4, _ = ctx.get_timing(sc.K_ASTAR)
+        ms_e4 = ctx.get_timing(sc.K_EDT_COLBITS)[0] + ctx.get_timing(sc.K_EDT_BAND)[0]
+        ctx.set_timing(False)
         ex4 = ctx.astar_last_expansions()
         st4 = o4["status"].cpu().numpy()
-        result["config3_one_gpu_share"] = {"workload": f"{W4}x{H4} {args.map} grid, EDT + A*, {Q4} queries (one GPU's block of the 64k), Lmax {L4}",
+        ln4 = o4["len"].cpu().numpy()
+        # the gathered result against the call's own outputs: lengths, statuses, offsets, a sample of the paths cell for cell
+        off4 = ga4["offsets"].cpu().numpy()
+        ok4 = bool(np.array_equal(ga4["len"].cpu().numpy(), ln4) and np.array_equal(ga4["status"].cpu().numpy(), st4) and int(ga4["truncated"][0]) == 0
+                   and off4[-1] == int(np.where(st4 == 0, ln4, 0).sum()))
+        c4 = ga4["cells"].cpu().numpy()
+        p4 = o4["path"][::64].cpu().numpy()
+        for qi, q in enumerate(range(0, Q4, 64)):
+            if st4[q] == 0:
+                ok4 = ok4 and np.array_equal(c4[off4[q]:off4[q] + ln4[q]], p4[qi, :ln4[q]])
+        result["config3_one_gpu_share"] = {"workload": f"{W4}x{H4} {args.map} grid, EDT + A* + gather of the paths, {Q4} queries (one GPU's block of the 64k), Lmax {L4}",
                                            "ms": dt4 * 1e3, "plans_per_s": Q4 / dt4, "expansions": int(ex4), "G_expansions_per_s": ex4 / dt4 / 1e9,
+                                           "ms_edt": ms_e4, "ms_astar": ms_a4,
                                            "found": int((st4 == 0).sum()), "truncated": int((st4 == 3).sum()), "ring_overflow": int((st4 == 4).sum()),
+                                           "mean_path_cells": float(ln4[st4 == 0].mean()) if (st4 == 0).any() else 0.0,
+                                           "gather": {"transport": "ncclAllGather (RCCL, world 1)" if use_gather else "none (sc_gather_pack -> sc_gather_unpack on the same message)",
+                                                      "cap_cells": cap4, "cap_cells_rule": "1.25 x the cells of the previous batch's paths + 1024",
+                                                      "message_bytes_per_rank": 4 * words4, "bytes_received_per_rank_at_8_ranks": 8 * 4 * words4,
+                                                      "fixed_stride_bytes_per_rank": Q4 * (L4 + 3) * 4,
+                                                      "ms_pack_and_unpack": ms_g4, "launch_groups": n_g4, "gathered_equals_own_results": ok4},
                                            "note": "the 8-GPU job gathers 8 such blocks with sc_allgather_paths; not measured on more than one GPU"}
-        del occ4, d4, o4
+        assert ok4, "config3: gathered paths differ from the call's own results"
+        del occ4, d4, o4, ga4, msg4
 
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -500,13 +577,24 @@ def main():
         pth = out["path"].cpu().numpy()
         ok = bool(np.array_equal(ref0["status"], st) and np.array_equal(ref0["cost"], out["cost"].cpu().numpy())
                   and all(np.array_equal(pth[q, :ref0["len"][q]], ref0["path"][q, :ref0["len"][q]]) for q in range(Qloc)))
+        # ... and of a step other than step 0 of the same library call: its own grid and query block
+        hl = main_run["_host"]
+        ok_last = None
+        if hl["lastk"] > 0:
+            d2_l = oracle.edt(hl["occ_last"])
+            ref_l = oracle.astar_batch(d2_l, hl["s_last"], hl["g_last"], Lmax=args.lmax, nthreads=cores)
+            o_l = hl["out_last"]
+            p_l = o_l["path"].cpu().numpy()
+            ok_last = bool(np.array_equal(ref_l["status"], o_l["status"].cpu().numpy()) and np.array_equal(ref_l["cost"], o_l["cost"].cpu().numpy())
+                           and all(np.array_equal(p_l[q, :ref_l["len"][q]], ref_l["path"][q, :ref_l["len"][q]]) for q in range(Qloc)))
         result["cpu_baseline"] = {"value": nq / (k * t_edt + t_as), "unit": "plans/s", "cores": cores, "kind": "port",
                                   "sample": f"{k} query sets of {Qloc} (exact EDT of the grid per set: {t_edt:.3f} s, 1 thread; "
                                             f"A* on {cores} threads: {t_as:.1f} s in total); build's own C restatement -- "
                                             "the reference has no grid path",
                                   "edt_seconds_1thread": t_edt, "astar_expansions": nexp,
                                   "single_thread_value": 128 / (t_edt * 128 / Qloc + t_1),
-                                  "gpu_matches_cpu_on_sample": ok}
+                                  "gpu_matches_cpu_on_sample": ok,
+                                  "gpu_matches_cpu_on_step": {"step_of_the_call": hl["lastk"], "matches": ok_last}}
     if rank == 0:
         print(json.dumps(result))
     for c in ctxs:

@@ -17,7 +17,7 @@ def _run(extra, env=None):
     e = dict(os.environ)
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--only-main-map",
-                        "--replan-frames", "0"] + extra, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+                        "--replan-frames", "0", "--repeats", "3"] + extra, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines            # exactly one line on stdout
@@ -35,6 +35,11 @@ def test_bench_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac"] > 0.3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_cpu_on_sample"] is True
+    # the steps of a call are distinct batches (own grid, own queries): a step other than step 0 is checked against the oracle too
+    assert c["gpu_matches_cpu_on_step"]["step_of_the_call"] == 3 and c["gpu_matches_cpu_on_step"]["matches"] is True
+    assert d["repeats"] >= 3 and d["value_min"] <= d["value"] <= d["value_max"] and len(d["ms_per_region"]) == d["repeats"]
+    assert d["config"]["queries_per_launch"] == 4 * d["config"]["queries_per_gpu"] and d["value_depth1"] > 0
+    assert d["per_query_depth1"]["kilocycles_max"] >= d["per_query_depth1"]["kilocycles_p99"] >= d["per_query_depth1"]["kilocycles_p50"] > 0
 
 
 def test_bench_gather_path_world1():
