@@ -294,6 +294,7 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 // later levels is then in their rings) before it picks the next level.  No barrier per step -- the two earlier
 // multi-wavefront forms (tools/microbench/astar_*_experiment.hip.txt) lost exactly there.
 #define HQ 256   // records of the hand-over ring
+#define ASTAR_SPIN_LIMIT (1 << 20)   // polls (about 100 cycles each) wavefront 0 waits for wavefront 1 before it gives the query up
 template <typename GT, bool DUAL>
 __device__ __forceinline__ void astar_query(const astar_args& a, const int q, const int slot) {
     __shared__ uint32_t qe[CQ];            // LDS ring of the current f level
@@ -303,7 +304,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __shared__ uint32_t nd_mv[64];
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
-    __shared__ uint8_t dup_tbl[DUAL ? 1024 : 1];   // DUAL: who pops cell (x + 32 y) mod 1024 in this step
+    __shared__ uint32_t dup_tbl[DUAL ? 1024 : 1];  // DUAL: the node last popped under hash (x + 32 y) mod 1024 (y << 16 | x, lane in the spare bits)
     __shared__ uint2 hq_rec[DUAL ? HQ : 1];   // hand-over ring: (node y << 16 | x, moves | legal moves << 8)
     __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found, hq_flush;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
@@ -344,6 +345,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     __builtin_amdgcn_wave_barrier();   // the previous query's last LDS reads are done before the rings are reset
     if (wv == 0 && lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
     if (wv == 0) prune_tbl[lane] = (uint8_t)entry_prune((uint32_t)lane << 13);
+    if (DUAL)
+        for (int i = threadIdx.x; i < 1024; i += 128) dup_tbl[i] = 0xFFFFFFFFu;   // no node popped yet in this search
     int fcur = octile(sx, sy, gx, gy);
     if (wv == 0 && lane == 0) {
         qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
@@ -362,8 +365,11 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     unsigned long long t_last = t_begin;
     int nwide = 0, nrounds = 0, n_qfull = 0, n_lvl = 0, b_batches = 0, b_records = 0, b_idle = 0;
 #endif
-    // Every step pops at least one entry and a search pushes at most 8 entries per cell: a bound that a correct
-    // search cannot reach, so that no wavefront can spin forever whatever the state of its scratch memory.
+    // Every step pops at least one entry and a search pushes at most 8 entries per cell: a bound that a correct search
+    // cannot reach.  It bounds wavefront 0's pop loop; its two waits on wavefront 1 (a full hand-over ring, the end of a
+    // level) give up after ASTAR_SPIN_LIMIT polls -- wavefront 1 needs microseconds for a full ring -- and end the query as
+    // SC_Q_RING_OVERFLOW, which the retry pass takes over; wavefront 1's own poll loop ends when wavefront 0 sets hq_stop,
+    // which it does on every way out.  So no wavefront can spin forever whatever the state of its scratch memory.
     int steps_left = (int)(8 * cells + 1024 < 0x7FFFFFFF ? 8 * cells + 1024 : 0x7FFFFFFF);
 
     // this lane's move in the 8-lanes-per-node form
@@ -403,6 +409,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         const unsigned long long wm = __ballot(rec);
         if (wm) {
             const int cnt = __popcll(wm);
+            int waited = 0;
             while (__builtin_expect(hq_tl + cnt - hq_hd > HQ, 0)) {     // wavefront 1 is a whole ring behind (as far as we know): look again
                 hq_hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_head, __ATOMIC_RELAXED, SCOPE));
                 if (hq_tl + cnt - hq_hd > HQ) {
@@ -410,6 +417,10 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
                     ++n_qfull;
 #endif
+                    if (++waited > ASTAR_SPIN_LIMIT) {   // a lost hand-over must not hang the queue: the query ends as a ring overflow
+                        ovf = true; steps_left = -1;
+                        return wm;
+                    }
                 }
             }
             if (rec) {
@@ -423,18 +434,28 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         return wm;
     };
     // DUAL, wavefront 0: among the `is` lanes (each pops node (hx, hy), entry he) find one representative per node.
-    // 0 = representative, 1 = the same node is popped by another lane of this step (dropped, as a lost atomic would be),
-    // 2 = lost its table slot to a DIFFERENT node: its entry goes back into the ring for the next step.
+    // 0 = representative, 1 = dropped: the same node is popped by another lane of this step, or it is the node that was
+    // popped under this hash most recently (closed then, whatever the bitmap word read in this step says), 2 = lost its
+    // table slot to a DIFFERENT node: its entry goes back into the ring for the next step.
+    // The table keeps the exact node per slot across steps.  That closes the one window in which the closed test would
+    // rest on how the memory system orders a wave's own operations: the OR that sets a node's bit in step t is not waited
+    // for, and a duplicate of that node popped in step t + 1 loads the word in the same step-t+1 burst -- it is caught
+    // here instead (its slot still holds the node: a step admits one node per slot).  From step t + 2 on the load is issued
+    // behind step t + 1's s_waitcnt vmcnt(0), which the OR of step t has completed by then (vmcnt counts atomics).
+    constexpr uint32_t DUP_KEY = 0x1FFF1FFFu, DUP_EMPTY = 0xFFFFFFFFu;
     auto dup_settle = [&](const bool is, const int hx, const int hy, const uint32_t he) {
         const int h = (hx + 32 * hy) & 1023;
-        if (is) dup_tbl[h] = (uint8_t)lane;
+        const uint32_t key = (uint32_t)hy << 16 | (uint32_t)hx;
+        const uint32_t mine = key | ((uint32_t)(lane & 7) << 13) | ((uint32_t)(lane >> 3) << 29);
+        const uint32_t before = is ? dup_tbl[h] : DUP_EMPTY;                       // what earlier steps left there
+        const bool closed_before = before != DUP_EMPTY && ((before ^ key) & DUP_KEY) == 0u;
+        const bool cand = is && !closed_before;
+        if (cand) dup_tbl[h] = mine;
         wave_lds_sync();
-        const int w = is ? (int)dup_tbl[h] : lane;
-        int res = 0;
-        if (__ballot(w != lane)) {
-            const uint32_t key = (uint32_t)hy << 16 | (uint32_t)hx;
-            const uint32_t okey = (uint32_t)__shfl((int)key, w);
-            res = w == lane ? 0 : (okey == key ? 1 : 2);
+        const uint32_t now = cand ? dup_tbl[h] : mine;
+        int res = closed_before ? 1 : 0;
+        if (__ballot(now != mine)) {
+            if (now != mine) res = ((now ^ key) & DUP_KEY) == 0u ? 1 : 2;
             const bool back = res == 2;
             const unsigned long long mb = __ballot(back);
             if (mb) {
@@ -817,11 +838,12 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             // every node of this level has been handed over: wait until wavefront 1 has pushed what follows from them
             STAMP(0);
             if (a.lazy && lane == 0) __hip_atomic_store(&hq_flush, hq_tl, __ATOMIC_RELAXED, SCOPE);
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl) {
+            for (int waited = 0; __builtin_amdgcn_readfirstlane(__hip_atomic_load(&hq_clean, __ATOMIC_RELAXED, SCOPE)) != hq_tl;) {
                 __builtin_amdgcn_s_sleep(1);
 #ifdef ASTAR_STAMPS
                 ++n_lvl;
 #endif
+                if (++waited > ASTAR_SPIN_LIMIT) { ovf = true; break; }   // as above: never expected, never a hang
             }
             wave_lds_sync();
             if (__hip_atomic_load(&hq_ovf, __ATOMIC_RELAXED, SCOPE)) ovf = true;

@@ -126,6 +126,10 @@ class Context:
     """One sc_ctx: one GPU, one stream.  `device` is the HIP device ordinal."""
 
     def __init__(self, device=0, use_torch_stream=True):
+        # torch brings its own HIP runtime: let it initialise first, so that the library binds to the runtime that is already
+        # in the process (loaded the other way round, the second runtime finds no GPU)
+        import torch
+        torch.cuda.is_available()
         self._l = lib()
         h = C.c_void_p()
         st = self._l.sc_ctx_create(device, C.byref(h))

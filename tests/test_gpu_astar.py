@@ -20,13 +20,19 @@ def _run(ctx, d2, s, g, r2=0, Lmax=4096):
     import torch
     out = ctx.astar_batch(torch.from_numpy(d2).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), r2=r2, Lmax=Lmax)
     torch.cuda.synchronize()
-    return {k: v.cpu().numpy() for k, v in out.items()}
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    got["expanded"] = ctx.astar_debug_stats(s.shape[0])[0]      # nodes every search expanded
+    return got
 
 
 def _compare(gpu, ref, Q):
     assert np.array_equal(gpu["status"], ref["status"])
     assert np.array_equal(gpu["cost"], ref["cost"])
     assert np.array_equal(gpu["len"], ref["len"])
+    if "expanded" in gpu:
+        # the search expands exactly E = {n : g*(n) + h(n) <= C*}: a node expanded twice (a stale closed bit) or a pruned
+        # one that should not have been shows here even when the path comes out right
+        assert np.array_equal(gpu["expanded"], ref["expanded"]), np.flatnonzero(gpu["expanded"] != ref["expanded"])[:8]
     for q in range(Q):
         if ref["status"][q] == 0:
             L = ref["len"][q]
@@ -125,7 +131,9 @@ def test_astar_4096_config3(ctx, oracle):
     out = ctx.astar_batch(d2, torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), Lmax=16384)
     torch.cuda.synchronize()
     ref = oracle.astar_batch(d2h, s, g, Lmax=16384, nthreads=16)
-    _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 64)
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    got["expanded"] = ctx.astar_debug_stats(64)[0]
+    _compare(got, ref, 64)
     assert (ref["status"] == 0).all() and ref["len"].max() > 2048
 
 
@@ -148,6 +156,7 @@ def test_astar_multi_grid_launch(ctx, oracle):
                                 torch.from_numpy(g).cuda(), Lmax=2048)
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in out.items()}
+    got["expanded"] = ctx.astar_debug_stats(s.shape[0])[0]
     for k, d2 in enumerate(d2s):
         sel = np.flatnonzero(qgrid == k)
         ref = oracle.astar_batch(d2, s[sel], g[sel], Lmax=2048, nthreads=4)
