@@ -212,6 +212,11 @@ int sc_bezier_from_path_batch(sc_ctx* ctx, const float* path, const int32_t* npt
                               const float* lines, int nlines, float* ctrl);
 int sc_bezier_from_path_batch_host(sc_ctx* ctx, const float* path, const int32_t* npts, int P, int n_max, float start_angle,
                                    const float* lines, int nlines, float* ctrl);
+/* bezier_spline::shrink_tangent (sea_current.hpp:575-596) on its own: tangent i becomes k * T[i], cut where the stretch
+ * Wp[i] +- k T[i] crosses an obstacle edge (edges in order, the shortened tangent carried from edge to edge as the
+ * reference does).  T, Wp, out float [M][2]; lines float [nlines][4]. */
+int sc_bezier_shrink_tangent_batch(sc_ctx* ctx, const float* T, const float* Wp, int M, float k, const float* lines, int nlines, float* out);
+int sc_bezier_shrink_tangent_batch_host(sc_ctx* ctx, const float* T, const float* Wp, int M, float k, const float* lines, int nlines, float* out);
 /* Point (order 0), hodograph (1) or second derivative (2) of segment seg[i] (index
  * into ctrl viewed as [S][4][2]) at parameter t[i]; out float [M][2].  Takes over
  * bezier_spline::bezier_curve (:700-763) and ::hodograph (:1041-1053). */

@@ -38,6 +38,15 @@ static void shrink(double* tx, double* ty, double wx, double wy, const float* li
     }
 }
 
+/* shrink_tangent on its own (:575-596): out[i] = k * T[i] cut against the edges at waypoint Wp[i] */
+void sco_bezier_shrink_tangent(const float* T, const float* Wp, int M, float k, const float* lines, int nlines, float* out) {
+    for (int i = 0; i < M; ++i) {
+        double tx = (double)k * (double)T[2 * i], ty = (double)k * (double)T[2 * i + 1];
+        shrink(&tx, &ty, (double)Wp[2 * i], (double)Wp[2 * i + 1], lines, nlines);
+        out[2 * i] = (float)tx; out[2 * i + 1] = (float)ty;
+    }
+}
+
 /* path: n waypoints (x,y); lines: nlines obstacle edges (x0,y0,x1,y1); start_angle NaN = along the first
  * leg (:605-609).  ctrl: [n-1][4][2] control points of the cubic per leg. */
 void sco_bezier_from_path(const float* path, int n, float start_angle, const float* lines, int nlines, float* ctrl) {

@@ -25,7 +25,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libsc_oracle.so")
+        path = os.environ.get("SC_ORACLE_LIB") or os.path.join(_HERE, "libsc_oracle.so")   # SC_ORACLE_LIB: the sanitizer build (make asan)
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
@@ -147,6 +147,17 @@ def bezier_from_path(path, start_angle=float("nan"), lines=None):
     lib().sco_bezier_from_path(_p(path, C.c_float), C.c_int(n), C.c_float(start_angle), _p(lines, C.c_float),
                                C.c_int(lines.shape[0]), _p(ctrl, C.c_float))
     return ctrl
+
+
+def bezier_shrink_tangent(T, Wp, k, lines):
+    """T, Wp [M,2] float32, lines [E,4] -> shrunk tangents [M,2] (sea_current.hpp:575-596)."""
+    T = np.ascontiguousarray(T, dtype=np.float32)
+    Wp = np.ascontiguousarray(Wp, dtype=np.float32)
+    lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(T)
+    lib().sco_bezier_shrink_tangent(_p(T, C.c_float), _p(Wp, C.c_float), C.c_int(T.shape[0]), C.c_float(k), _p(lines, C.c_float),
+                                    C.c_int(lines.shape[0]), _p(out, C.c_float))
+    return out
 
 
 def bezier_eval(ctrl, seg, t, order=0):

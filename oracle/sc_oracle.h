@@ -109,6 +109,9 @@ int sco_toppra_sample(int dof, int N, const double* p0, const double* p1,
 /* from_path (sea_current.hpp:599-683): n waypoints (x,y) -> ctrl [n-1][4][2]; lines [nlines][4] obstacle edges
  * for shrink_tangent (:575-596); start_angle NaN = along the first leg. */
 void sco_bezier_from_path(const float* path, int n, float start_angle, const float* lines, int nlines, float* ctrl);
+/* bezier_spline::shrink_tangent (:575-596) on its own: out[i] = k * T[i] cut where Wp[i] +- that tangent crosses an edge
+ * (edges in order, the shortened tangent carried along).  No recorded output: checked against closed forms. */
+void sco_bezier_shrink_tangent(const float* T, const float* Wp, int M, float k, const float* lines, int nlines, float* out);
 /* order 0: point, 1: hodograph (:1041-1053), 2: second derivative; out [m][2] */
 void sco_bezier_eval(const float* ctrl, const int* seg, const double* t, int m, int order, double* out);
 /* arclength (:767-896): GL-32 on nsub sub-intervals per segment; cum [nseg][nsub+1]; returns the total */

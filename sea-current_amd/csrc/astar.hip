@@ -1077,13 +1077,27 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     if (slots > resident) slots = resident;
     if (slots > (size_t)Q) slots = Q;
     if (slots < 1) slots = 1;
-    r = sc_scratch_reserve(ctx, &ctx->gslots, slots * gcells * gsz);
-    if (r != SC_OK) return r;
-    r = sc_scratch_reserve(ctx, &ctx->closed, slots * bwords * 4);
-    if (r != SC_OK) return r;
-    // at least 16 slots' worth of rings, so that the retry pass has 16x the space even for a single query
-    r = sc_scratch_reserve(ctx, &ctx->buckets, (slots > 16 ? slots : 16) * NBUCKET * (size_t)cap * 4);
-    if (r != SC_OK) return r;
+    // The budget above is per context; the memory is the device's.  When the slot scratch has to grow, what the device
+    // has free right now (plus what this context's own slot scratch gives back when it is reallocated) bounds it too --
+    // two contexts planning on 4096^2 grids would otherwise ask for 2 x 96 of the 288 GB -- and an allocation that
+    // fails all the same halves the slots and tries again: fewer resident searches, never an error while one fits.
+    auto ring_slots = [](size_t n) { return n > 16 ? n : (size_t)16; };   // >= 16 slots' worth of rings: the retry pass's 16x
+    if (slots * gcells * gsz > ctx->gslots.bytes || slots * bwords * 4 > ctx->closed.bytes || ring_slots(slots) * NBUCKET * (size_t)cap * 4 > ctx->buckets.bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = (size_t)(0.9 * (double)(free_b + ctx->gslots.bytes + ctx->closed.bytes + ctx->buckets.bytes));
+            while (slots > 1 && slots * (gcells * gsz + bwords * 4) + ring_slots(slots) * NBUCKET * (size_t)cap * 4 > avail) slots = (slots + 1) / 2;
+        }
+    }
+    for (;;) {
+        r = sc_scratch_reserve(ctx, &ctx->gslots, slots * gcells * gsz);
+        if (r == SC_OK) r = sc_scratch_reserve(ctx, &ctx->closed, slots * bwords * 4);
+        if (r == SC_OK) r = sc_scratch_reserve(ctx, &ctx->buckets, ring_slots(slots) * NBUCKET * (size_t)cap * 4);
+        if (r == SC_OK) break;
+        if (r != SC_ERR_NOMEM || slots <= 1) return r;
+        (void)hipGetLastError();   // the failed allocation is handled here
+        slots = (slots + 1) / 2;
+    }
     if (!ctx->actr.p) {
         r = sc_scratch_reserve(ctx, &ctx->actr, 16 * sizeof(int32_t));
         if (r != SC_OK) return r;

@@ -469,6 +469,28 @@ extern "C" int sc_bezier_from_path_batch(sc_ctx* ctx, const float* path, const i
     return SC_OK;
 }
 
+// bezier_spline::shrink_tangent (sea_current.hpp:575-596) on its own: M tangents k * T at waypoints Wp against the edges
+__global__ void __launch_bounds__(256)
+bezier_shrink_kernel(const float* __restrict__ T, const float* __restrict__ Wp, int M, float k, const float* __restrict__ lines, int nlines,
+                     float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    double tx = (double)k * (double)T[2 * i], ty = (double)k * (double)T[2 * i + 1];
+    shrink(tx, ty, (double)Wp[2 * i], (double)Wp[2 * i + 1], lines, nlines);
+    out[2 * i] = (float)tx; out[2 * i + 1] = (float)ty;
+}
+
+extern "C" int sc_bezier_shrink_tangent_batch(sc_ctx* ctx, const float* T, const float* Wp, int M, float k, const float* lines, int nlines,
+                                              float* out) {
+    if (!ctx || !T || !Wp || !out || M <= 0 || nlines < 0 || (nlines > 0 && !lines)) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int tk = sc_time_begin(ctx, SC_K_BEZIER);
+    hipLaunchKernelGGL(bezier_shrink_kernel, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, T, Wp, M, k, lines, nlines, out);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 extern "C" int sc_bezier_eval_batch(sc_ctx* ctx, const float* ctrl, const int32_t* seg, const float* t, int M, int order, float* out) {
     if (!ctx || !ctrl || !seg || !t || !out || M <= 0 || order < 0 || order > 2) return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));

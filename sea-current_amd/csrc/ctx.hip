@@ -393,6 +393,23 @@ extern "C" int sc_bezier_eval_batch_host(sc_ctx* ctx, const float* ctrl, int S, 
     return sc_ctx_synchronize(ctx);
 }
 
+extern "C" int sc_bezier_shrink_tangent_batch_host(sc_ctx* ctx, const float* T, const float* Wp, int M, float k, const float* lines, int nlines,
+                                                   float* out) {
+    if (!ctx || !T || !Wp || !out || M <= 0 || nlines < 0 || (nlines > 0 && !lines)) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t mb = ((size_t)M * 8 + 255) & ~(size_t)255, lb = ((size_t)nlines * 16 + 255) & ~(size_t)255;
+    STAGE(5, 3 * mb + lb);
+    char* b = (char*)ctx->staging[5].p;
+    SC_HIP(ctx, hipMemcpyAsync(b, T, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(b + mb, Wp, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nlines) SC_HIP(ctx, hipMemcpyAsync(b + 2 * mb, lines, (size_t)nlines * 16, hipMemcpyHostToDevice, ctx->stream));
+    int r = sc_bezier_shrink_tangent_batch(ctx, (const float*)b, (const float*)(b + mb), M, k, nlines ? (const float*)(b + 2 * mb) : nullptr, nlines,
+                                           (float*)(b + 2 * mb + lb));
+    if (r != SC_OK) return r;
+    SC_HIP(ctx, hipMemcpyAsync(out, b + 2 * mb + lb, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_ctx_synchronize(ctx);
+}
+
 extern "C" int sc_fmt_star_batch_host(sc_ctx* ctx, const float* samples, int n, const float* starts, const float* goals, int Q, float rn,
                                       const float* lines, int E, int Lmax, float* path, int32_t* len, float* cost, int32_t* status) {
     if (!ctx || !samples || !starts || !goals || !path || !len || !cost || !status || n < 0 || Q < 0 || E < 0 || Lmax <= 0) return SC_ERR_INVALID;

@@ -46,7 +46,7 @@ struct sc_ctx {
     sc_scratch gather_msg;  // gather: this rank's message, every rank's messages, local offsets
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 16;          // ring entries per bucket (power of two)
-    size_t astar_slot_budget = (size_t)96 << 30;  // bytes of g + bitmap + ring scratch allowed (SC_ASTAR_SLOT_GB); 4096^2: 96 GiB = 1966 slots measured best (48: -34 %, 160: -17 %)
+    size_t astar_slot_budget = (size_t)96 << 30;  // bytes of g + bitmap + ring scratch this context may take (SC_ASTAR_SLOT_GB), further bounded by what the device has free; 4096^2: 96 GiB = 1966 slots measured best (48: -34 %, 160: -17 %)
     int last_Q = 0;
     int edt_chain_token = -1;       // timing: colbits' end event doubles as band's start event
     int edt_open_token = -1;        // timing: band bracket already opened (wide rows: in front of the updown launch)

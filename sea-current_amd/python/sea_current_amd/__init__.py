@@ -70,6 +70,8 @@ _SIGNATURES = {
     "sc_occ_from_rects": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sc_bezier_from_path_batch": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_from_path_batch_host": (_i, [_vp, _vp, _vp, _i, _i, C.c_float, _vp, _i, _vp]),
+    "sc_bezier_shrink_tangent_batch": (_i, [_vp, _vp, _vp, _i, C.c_float, _vp, _i, _vp]),
+    "sc_bezier_shrink_tangent_batch_host": (_i, [_vp, _vp, _vp, _i, C.c_float, _vp, _i, _vp]),
     "sc_bezier_eval_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sc_bezier_eval_batch_host": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "sc_bezier_curve_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),

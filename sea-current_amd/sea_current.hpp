@@ -39,6 +39,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -696,6 +697,29 @@ public:
             for (int r = 0; r < sp.n_pts(); ++r, ++o) { bs.pts(o, 0) = sp.pts(r, 0); bs.pts(o, 1) = sp.pts(r, 1); }
         }
         return bs;
+    }
+
+    // k * T, cut where the stretch W +- k T crosses an obstacle edge of `ps` (same signature as :401 / :575-596; the edge
+    // tests run on the GPU, sc_bezier_shrink_tangent_batch: what from_path applies to every waypoint's tangent)
+    static Vector2f shrink_tangent(const Vector2f& T, const Vector2f& W, const float k, const planning_space& ps,
+                                   gpu_context& ctx = default_context()) {
+        std::vector<float> lines;
+        for (const auto& ob : ps.obstacles)
+            for (const auto& [a, b] : ob.lines) { lines.push_back(a.x()); lines.push_back(a.y()); lines.push_back(b.x()); lines.push_back(b.y()); }
+        const float t[2] = {T.x(), T.y()}, w[2] = {W.x(), W.y()};
+        float out[2] = {k * T.x(), k * T.y()};
+        if (!lines.empty())
+            ctx.check(sc_bezier_shrink_tangent_batch_host(ctx.get(), t, w, 1, k, lines.data(), (int)(lines.size() / 4), out), "sc_bezier_shrink_tangent_batch_host");
+        return Vector2f(out[0], out[1]);
+    }
+
+    // the (degree + 1)-th roots of unity the reference's Bernstein-Fourier evaluation runs over (:422, :1096-1106): kept for
+    // callers that use it; curves are evaluated from their control points here
+    static inline std::vector<std::complex<float>> omega_table(const int degree) {
+        std::vector<std::complex<float>> omegas((size_t)degree + 1);
+        const double step = -2.0 * 3.14159265358979323846 / (double)(degree + 1);
+        for (int i = 0; i <= degree; ++i) omegas[(size_t)i] = std::complex<float>((float)std::cos(step * i), (float)std::sin(step * i));
+        return omegas;
     }
 
     // cubic Bezier spline through a piecewise-linear path; tangents by the Lau09 heuristics, shrunk against the

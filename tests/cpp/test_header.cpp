@@ -115,6 +115,20 @@ int main(int argc, char** argv) {
         CHECK(ad.segments.size() == 2 && ad.segments[0].rows() == 101);
         CHECK(std::fabs(ad.positions[0](100) - 1.0f) < 1e-6f);
     }
+    // --- shrink_tangent on its own (sea_current.hpp:575-596): a wall across the tangent cuts it there; from_path applies the same ---
+    {
+        planning_space walled(bounding_rect{10, -10, 10, -10});
+        walled.obstacles = {obstacle({Vector2f(2, -1), Vector2f(2, 1), Vector2f(3, 1), Vector2f(3, -1)})};
+        const Vector2f cut = bezier_spline::shrink_tangent(Vector2f(10, 0), Vector2f(0, 0), 0.5f, walled);
+        CHECK(std::fabs(cut.x() - 2.0f) < 1e-6f && std::fabs(cut.y()) < 1e-6f);
+        const Vector2f kept = bezier_spline::shrink_tangent(Vector2f(0, 3), Vector2f(0, 0), 0.5f, walled);
+        CHECK(kept.x() == 0.0f && kept.y() == 1.5f);
+        bezier_spline pad = bezier_spline::from_path({Vector2f(0, 0), Vector2f(1.9f, 0), Vector2f(1.9f, 8)}, walled, 0.0f);
+        CHECK(pad.ctrl_pts[0][1].x() <= 2.0f + 1e-6f);
+        const auto om = bezier_spline::omega_table(3);      // the 4th roots of unity, clockwise (:1096-1106)
+        CHECK(om.size() == 4 && std::abs(om[0] - std::complex<float>(1, 0)) < 1e-6f && std::abs(om[1] - std::complex<float>(0, -1)) < 1e-6f &&
+              std::abs(om[2] - std::complex<float>(-1, 0)) < 1e-6f);
+    }
     // --- velocity profile: examples/zmq_test.cpp:69-88 with the recorded arclength of output.json ---
     const double L = 21.38861656188965;
     auto vel_lim = [&](value_type) {

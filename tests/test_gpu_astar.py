@@ -209,3 +209,37 @@ def test_astar_full_headline_batch(ctx, oracle):
     ref = oracle.astar_batch(d2h, s, g, Lmax=4096, nthreads=16)
     _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 1024)
     assert np.array_equal(ex, ref["expanded"])
+
+
+def test_astar_scratch_fits_what_the_device_has_free(oracle):
+    """The per-search scratch is budgeted per context but allocated on a shared device: with most of the HBM taken by
+    somebody else a large batch must still run -- on fewer resident searches -- and give the same results."""
+    import torch
+    import sea_current_amd as sc
+    from sea_current_amd import synth
+    occ = synth.salt_grid(2048, 2048, 0.2, seed=12)
+    Q = 2048
+    c = sc.Context(0)
+    try:
+        d2 = c.edt(torch.from_numpy(occ).cuda())
+        torch.cuda.synchronize()
+        d2h = d2.cpu().numpy()
+        s, g = synth.queries(d2h >= 1, Q, seed=12)
+        sd, gd = torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda()
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(max(0, free - (6 << 30)), dtype=torch.uint8, device="cuda")      # leave about 6 GiB: a fraction of the 17 GiB 2048 slots want
+        out = c.astar_batch(d2, sd, gd, Lmax=8192)
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in out.items()}
+        got_ex = c.astar_debug_stats(Q)[0]
+        assert c.scratch_bytes() < (6 << 30)
+        del hog
+        torch.cuda.empty_cache()
+    finally:
+        c.close()
+    assert (got["status"] == 0).all()
+    sel = np.arange(0, Q, 32)
+    ref = oracle.astar_batch(d2h, s[sel], g[sel], Lmax=8192, nthreads=16)
+    sub = {k: v[sel] for k, v in got.items()}
+    sub["expanded"] = got_ex[sel]
+    _compare(sub, ref, sel.shape[0])

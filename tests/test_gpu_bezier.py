@@ -187,3 +187,29 @@ def test_general_degree_curve_and_free_chebfit(ctx, oracle):
                 assert np.abs(yh[sl] - y_ref).max() < 5e-5 * max(1.0, np.abs(y_ref).max()), (degree, n)
                 if n >= 300:
                     assert np.abs(coef[b] - c_ref).max() < 1e-4 * max(1.0, np.abs(c_ref).max())
+
+
+def test_shrink_tangent_batch_matches_oracle(ctx, oracle):
+    """sc_bezier_shrink_tangent_batch(_host) (bezier_spline::shrink_tangent, sea_current.hpp:575-596) against the oracle on
+    random tangents, waypoints and walls, and against the hand-made cases of tests/test_oracle_bezier.py."""
+    import ctypes as C
+    import sea_current_amd as sc
+    rng = np.random.default_rng(5)
+    M, E = 500, 23
+    T = rng.uniform(-3, 3, (M, 2)).astype(np.float32)
+    Wp = rng.uniform(-5, 5, (M, 2)).astype(np.float32)
+    lines = rng.uniform(-6, 6, (E, 4)).astype(np.float32)
+    out = np.zeros((M, 2), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for k in (1.0, 0.4):
+        st = sc.lib().sc_bezier_shrink_tangent_batch_host(ctx._h, p(T), p(Wp), M, C.c_float(k), p(lines), E, p(out))
+        assert st == 0
+        ref = oracle.bezier_shrink_tangent(T, Wp, k, lines)
+        assert np.allclose(out, ref, rtol=1e-6, atol=1e-6)
+        assert (np.abs(ref - k * T).max(axis=1) > 1e-3).sum() > 20          # a good share of the tangents is actually cut
+    st = sc.lib().sc_bezier_shrink_tangent_batch_host(ctx._h, p(T), p(Wp), M, C.c_float(0.5), None, 0, p(out))
+    assert st == 0 and np.allclose(out, 0.5 * T)
+    one = np.zeros((1, 2), np.float32)
+    wall = np.array([[1.5, -1, 1.5, 1]], np.float32)
+    sc.lib().sc_bezier_shrink_tangent_batch_host(ctx._h, p(np.array([[4, 0]], np.float32)), p(np.zeros((1, 2), np.float32)), 1, C.c_float(0.5), p(wall), 1, p(one))
+    assert np.allclose(one, [[1.5, 0]])

@@ -139,3 +139,18 @@ def test_general_degree_curve_matches_bernstein_sum(oracle):
     assert np.allclose(oracle.bezier_curve(ctrl, seg, t), oracle.bezier_eval(ctrl, seg, t, 0), atol=1e-12)
     hod = (3 * (ctrl[:, 1:] - ctrl[:, :-1])).astype(np.float32)          # degree * (P[j+1] - P[j]), :1046
     assert np.allclose(oracle.bezier_curve(hod, seg, t), oracle.bezier_eval(ctrl, seg, t, 1), atol=1e-5)
+
+
+def test_shrink_tangent_on_its_own_closed_forms(oracle):
+    """sco_bezier_shrink_tangent (sea_current.hpp:575-596) against geometry done by hand: a wall in front of the tangent cuts it at
+    the wall, a wall behind the waypoint cuts it by the mirrored stretch, a far wall leaves k * T, two walls apply in order."""
+    T = np.array([[4, 0], [4, 0], [4, 0], [0, 3], [4, 0]], np.float32)
+    Wp = np.array([[0, 0], [0, 0], [0, 0], [1, 1], [0, 0]], np.float32)
+    wall = lambda x, y0, y1: [x, y0, x, y1]
+    # k = 0.5: the stretch W + 2 ex reaches x = 2
+    assert np.allclose(oracle.bezier_shrink_tangent(T[:1], Wp[:1], 0.5, [wall(1.5, -1, 1)]), [[1.5, 0]])           # cut at the wall
+    assert np.allclose(oracle.bezier_shrink_tangent(T[1:2], Wp[1:2], 0.5, [wall(-1.25, -1, 1)]), [[1.25, 0]])      # wall behind: W - T crosses it
+    assert np.allclose(oracle.bezier_shrink_tangent(T[2:3], Wp[2:3], 0.5, [wall(2.5, -1, 1)]), [[2.0, 0]])         # out of reach: k T
+    assert np.allclose(oracle.bezier_shrink_tangent(T[3:4], Wp[3:4], 1.0, [[0, 2.5, 2, 2.5]]), [[0, 1.5]])          # vertical tangent, horizontal wall
+    assert np.allclose(oracle.bezier_shrink_tangent(T[4:5], Wp[4:5], 0.5, [wall(1.5, -1, 1), wall(-1.0, -1, 1)]), [[1.0, 0]])   # first the front wall, then the rear one cuts further
+    assert np.allclose(oracle.bezier_shrink_tangent(T[:1], Wp[:1], 0.5, [[1.5, 0.5, 1.5, 2.0]]), [[2.0, 0]])        # the wall does not reach the tangent's line
