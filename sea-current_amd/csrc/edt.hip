@@ -35,12 +35,13 @@ __device__ __forceinline__ uint32_t nonzero_bytes_hi(uint32_t v) {
     return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
-// Fast path (W % 16 == 0): block = 64 column groups x 4 row groups of ONE band.  Thread (xg, rg)
+// Fast path (W % 16 == 0 with 16-byte loads, W % 4 == 0 with dword loads): block = 64 column groups x 4 row groups of ONE band.  Thread (xg, rg)
 // loads rows 8 rg .. 8 rg + 7 of 16 adjacent columns (8 independent 16-byte loads, issued back to
 // back: the block's requests are one contiguous 32 KiB burst, which keeps HBM row-buffer locality --
 // one thread walking all 32 rows gives 2048 concurrent 1-KiB streams 32 KiB apart and reads at
 // under half the rate), reduces them to 8 row bits per column, and the block transposes through
 // LDS so that every thread assembles and stores the 32-bit words of 4 adjacent columns.
+template <bool ALIGNED16>
 __global__ void __launch_bounds__(256)
 edt_colbits_kernel(const uint8_t* __restrict__ occ, int W, int H, int nb, uint32_t* __restrict__ colbits) {
     __shared__ uint4 sq[4][64];
@@ -52,9 +53,20 @@ edt_colbits_kernel(const uint8_t* __restrict__ occ, int W, int H, int nb, uint32
         const int row0 = b * 32 + rg * 8;
         const uint8_t* base = occ + ((size_t)g * H + row0) * W + x0;
         uint4 v[8];
+        if (ALIGNED16) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = row0 + i < H ? *reinterpret_cast<const uint4*>(base + (size_t)i * W) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 8; ++i)
+                v[i] = row0 + i < H ? *reinterpret_cast<const uint4*>(base + (size_t)i * W) : make_uint4(0, 0, 0, 0);
+        } else {
+            // W % 4 == 0 only: rows are dword-aligned; the last thread of a row may hold fewer than 16 columns
+            const int nd = min(4, (W - x0) >> 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t* r4 = reinterpret_cast<const uint32_t*>(base + (size_t)i * W);
+                const bool in = row0 + i < H;
+                v[i] = make_uint4(in && nd > 0 ? r4[0] : 0u, in && nd > 1 ? r4[1] : 0u, in && nd > 2 ? r4[2] : 0u, in && nd > 3 ? r4[3] : 0u);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             Q[0] |= (nonzero_bytes_hi(v[i].x) >> 7) << i;
@@ -695,6 +707,33 @@ edt_band_g8_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, i
     }
 }
 
+// ---- packed helpers shared by the 1024-wide and the wide-row kernels ----
+// v_pk_minimum3_f16 on bit patterns 0 .. 0x7C00 (non-negative f16, denormals included): the f16 order is the integer order
+// (tools/microbench/min3_mb.hip checks the instruction on 32 M triples), so the cascade step is two packed instructions per
+// register -- T = P + (2 it - 1), P = min3(P, T[left], T[right]) -- instead of three.  To stay below the NaN patterns the
+// distance bytes are clamped at 177 (packed values below 177^2 = 31329 are exact) and the cascade stops after 175 steps
+// (T <= 31329 + 349 < 0x7C00); rows that need more (very sparse grids) are redone in 32 bits.
+#define EDT_W_GCAP 177u
+#define EDT_W_ITMAX 175
+__device__ __forceinline__ uint32_t pk_min3_f16bits(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_wrap(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, b) + __builtin_bit_cast(us2_t, c)));
+}
+// lane l <- lane l-1, lane 0 <- lane 63 / lane l <- lane l+1, lane 63 <- lane 0
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C /*wave_ror:1*/, 0xF, 0xF, true);   // every lane is written: no old value
+}
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /*wave_rol:1*/, 0xF, 0xF, true);
+}
+
 // ---- edt_updown_kernel: per (band, column), rows to the nearest obstacle in the bands above / below -----------
 // ud[b][x] = up | dn << 16: up = rows from the band's FIRST row up to the nearest obstacle of an earlier band, dn = rows
 // from its LAST row down to the nearest obstacle of a later band (EDT_G_INF: none).  With it a band kernel needs two
@@ -761,34 +800,7 @@ static void launch_updown(sc_ctx* ctx, const uint32_t* colbits, int W, int nb, i
 // times a 1024-pixel one.  A workgroup owns 16 rows (half a band of column words: 64 KiB of distance bytes at W = 4096,
 // two workgroups per CU); each wave transposes through the LDS row it has already pulled into registers.
 //
-// The step itself is two packed instructions per register instead of three: T = P + (2 it - 1), then
-// P = min3(P, T[left], T[right]) with v_pk_minimum3_f16 -- on bit patterns 0 .. 0x7C00 (non-negative f16, denormals
-// included) the f16 order is the integer order (tools/microbench/min3_mb.hip checks the instruction on 32 M triples).
-// To stay below the NaN patterns the distance bytes are clamped at 177 (packed values below 177^2 = 31329 are exact) and
-// the cascade stops after 175 steps (T <= 31329 + 349 < 0x7C00); rows that need more (very sparse grids) are redone at
-// the end by a 32-bit outward scan over exact distances, in the LDS the distance bytes no longer need.
-#define EDT_W_GCAP 177u
-#define EDT_W_ITMAX 175
-__device__ __forceinline__ uint32_t pk_min3_f16bits(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_add_wrap(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
-}
-// lane l <- lane l-1, lane 0 <- lane 63 / lane l <- lane l+1, lane 63 <- lane 0
-__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C /*wave_ror:1*/, 0xF, 0xF, true);   // every lane is written: no old value
-}
-__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /*wave_rol:1*/, 0xF, 0xF, true);
-}
-
-__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * __builtin_bit_cast(us2_t, b) + __builtin_bit_cast(us2_t, c)));
-}
-
+// The cascade step, the clamp of the distance bytes at 177 and the 175-step limit are those of edt_band_k16_kernel (pk_min3_f16bits).
 // One workgroup per CU, 16 wavefronts, persistent over a strided set of row groups (16 rows each), and NO workgroup
 // barrier in the loop.  The distance bytes of a group live in one of two LDS slots.  Wavefronts 0-7 are PRODUCERS: each
 // owns an eighth of the columns and turns their column words into the distance bytes of the next group (vertical pass,
@@ -1131,6 +1143,264 @@ static int launch_band_wide_t(sc_ctx* ctx, const uint32_t* colbits, int W, int H
                              : launch_band_wide<TILES, false>(ctx, colbits, W, H, nb, batch, d2);
 }
 
+// ---- edt_band_k16_kernel: rows of 513 .. 1024 pixels (the headline width) -------------------------------------
+// edt_band_g8_kernel<16> with three changes (measured on the wide-row kernel first, whose LDS traffic was its bound):
+//  * the cascade step is add + min3 (two packed instructions per register instead of three, see pk_min3_f16bits);
+//  * the vertical pass is one packed multiply-add per row and direction (gu = free ? gu + 1 : 0 is (gu + 1) * free), the
+//    32 rows in two halves so that the running values stay in registers, and pairs of lanes exchange their 2 x 2 bytes so
+//    that every lane stores ONE dword per two rows instead of two 2-byte pieces each;
+//  * the transposition re-pairs the registers so that a dword holds two ADJACENT pixels: a 16-byte global store is then ONE
+//    8-byte LDS read (half the read traffic of reading packed registers back and keeping one half of every dword).
+template <bool FULL>
+__global__ void __launch_bounds__(512, 8)
+edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
+    constexpr int WAVES = 8, WP = 1024;
+    constexpr uint32_t GC2 = EDT_W_GCAP | (EDT_W_GCAP << 16);
+    constexpr uint32_t EDGE = 0x7BFF7BFFu;          // beyond the row ends: above every value, below the f16 NaN patterns
+    constexpr int UDCAP = 0x7000;                   // "no obstacle" for up / dn: still a non-negative finite f16 pattern after + 32
+    extern __shared__ uint32_t smem[];
+    uint8_t* g8 = reinterpret_cast<uint8_t*>(smem);            // [32][WP] vertical distances, clamped at EDT_W_GCAP
+    uint32_t* trs = smem + 32 * WP / 4;                        // [WAVES][256] transposition buffers (half of what a wave needs)
+    const unsigned nwg = gridDim.x, per = nwg >> 3;
+    const unsigned vid = blockIdx.x < (per << 3) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int b = (int)(vid % (unsigned)nb), g = (int)(vid / (unsigned)nb);
+    const uint32_t* cb = colbits + (size_t)g * nb * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- phase 1: two adjacent columns per thread -> 32 rows of 2 distance bytes ----
+    {
+        const int q = threadIdx.x;
+        uint32_t w[2], wu[2][4], wd[2][4];
+        int up[2], dn[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int x = 2 * q + c;
+            const bool in = FULL || x < W;
+            w[c] = in ? cb[(size_t)b * W + x] : 0u;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wu[c][t] = (in && b - 1 - t >= 0) ? cb[(size_t)(b - 1 - t) * W + x] : 0u;
+                wd[c][t] = (in && b + 1 + t < nb) ? cb[(size_t)(b + 1 + t) * W + x] : 0u;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int x = 2 * q + c;
+            up[c] = EDT_G_INF; dn[c] = EDT_G_INF;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (up[c] == EDT_G_INF && wu[c][t]) up[c] = (t + 1) * 32 - (31 - __clz((int)wu[c][t]));
+                if (dn[c] == EDT_G_INF && wd[c][t]) dn[c] = (t + 1) * 32 + (__ffs((int)wd[c][t]) - 1) - 31;
+            }
+            if (FULL || x < W) {
+                for (int base = b - 5; base >= 0 && up[c] == EDT_G_INF; base -= 4) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ww[t] = base - t >= 0 ? cb[(size_t)(base - t) * W + x] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (up[c] == EDT_G_INF && ww[t]) up[c] = (b - (base - t)) * 32 - (31 - __clz((int)ww[t]));
+                }
+                for (int base = b + 5; base < nb && dn[c] == EDT_G_INF; base += 4) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ww[t] = base + t < nb ? cb[(size_t)(base + t) * W + x] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (dn[c] == EDT_G_INF && ww[t]) dn[c] = ((base + t) - b) * 32 + (__ffs((int)ww[t]) - 1) - 31;
+                }
+            }
+            up[c] = min(up[c], UDCAP); dn[c] = min(dn[c], UDCAP);
+        }
+        // free01 of row i: 1 per half whose cell is free (rows 0..15 of both columns from nwA, 16..31 from nwB)
+        const uint32_t nw0 = ~w[0], nw1 = ~w[1];
+        const uint32_t nwA = (nw0 & 0xFFFFu) | (nw1 << 16), nwB = (nw0 >> 16) | (nw1 & 0xFFFF0000u);
+        const uint32_t psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+        uint8_t* dst = g8 + (size_t)(lane & 1) * WP + 2 * (q & ~1);
+        uint32_t GU[16];
+        // top-down over all 32 rows, keeping rows 16..31; bottom-up over them; the same for rows 0..15 (their top-down run
+        // again from the band's top: 16 multiply-adds instead of 16 more registers; the free bits are extracted again on the
+        // way up for the same reason: the kernel has to stay within 64 VGPRs for its eight wavefronts per SIMD)
+        uint32_t gu = (uint32_t)(up[0] - 1) | ((uint32_t)(up[1] - 1) << 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t f = (nwA >> i) & 0x00010001u;
+            gu = pk_mad_u16(gu, f, f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t f = (nwB >> i) & 0x00010001u;
+            gu = pk_mad_u16(gu, f, f);
+            GU[i] = gu;
+        }
+        uint32_t gd = (uint32_t)(dn[0] - 1) | ((uint32_t)(dn[1] - 1) << 16);
+#pragma unroll
+        for (int half = 1; half >= 0; --half) {
+            uint32_t nwH = half ? nwB : nwA, nwT = nwA;
+            asm("" : "+v"(nwH), "+v"(nwT));   // fresh values to the compiler: it would otherwise keep all 32 extracted words alive (spills)
+            if (half == 0) {
+                gu = (uint32_t)(up[0] - 1) | ((uint32_t)(up[1] - 1) << 16);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t f = (nwT >> i) & 0x00010001u;
+                    gu = pk_mad_u16(gu, f, f);
+                    GU[i] = gu;
+                }
+            }
+#pragma unroll
+            for (int i = 14; i >= 0; i -= 2) {
+                const uint32_t f1 = (nwH >> (i + 1)) & 0x00010001u, f0 = (nwH >> i) & 0x00010001u;
+                gd = pk_mad_u16(gd, f1, f1);
+                const uint32_t g1 = pk_min3_f16bits(GU[i + 1], gd, GC2);
+                gd = pk_mad_u16(gd, f0, f0);
+                const uint32_t g0 = pk_min3_f16bits(GU[i], gd, GC2);
+                const uint32_t own = __builtin_amdgcn_perm(g1, g0, 0x06040200u);   // bytes: row i (col 0, col 1), row i + 1 (col 0, col 1)
+                const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, true);
+                *reinterpret_cast<uint32_t*>(dst + (size_t)(16 * half + i) * WP) = __builtin_amdgcn_perm(oth, own, psel);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int y0 = b * 32;
+    const int nrows = min(32, H - y0);
+    const int nvalid = W - 16 * lane;
+    // a wave's transposition buffer: 1 KiB of its own (lanes 0..31) plus the first KiB of the g8 row it processes first
+    // (lanes 32..63), dead once the wave has pulled that row into registers
+    uint32_t* tr = trs + (size_t)wave * 256;
+    uint32_t* trb = smem + (size_t)wave * (WP / 4) - 256;      // trb[8 * lane + r] with lane >= 32 lands in row `wave`
+    int hint = 4;
+    for (int i = wave; i < nrows; i += WAVES) {
+        int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
+        uint32_t P[8];
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(g8 + (size_t)i * WP + 16 * lane);
+            const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t sel = 0x0C000C00u | (uint32_t)(j % 4) | ((uint32_t)(4 + j % 4) << 16);
+                const uint32_t tt = __builtin_amdgcn_perm(dw[(j + 8) / 4], dw[j / 4], sel);
+                P[j] = pk_mul_lo(tt, tt);      // <= 177^2: pixels past the row end carry 177 ("no obstacle")
+            }
+        }
+        auto cascade_step = [&](int it) {
+            const uint32_t c = (uint32_t)(2 * it - 1) * 0x00010001u;
+            uint32_t T[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) T[j] = pk_add_wrap(P[j], c);
+            const uint32_t lo = wave_ror1(T[7]), hi = wave_rol1(T[0]);
+            const uint32_t below = lane == 0 ? EDGE : lo, above = lane == 63 ? EDGE : hi;
+            const uint32_t L0 = __builtin_amdgcn_alignbit(T[7], below, 16);   // T of the left neighbours of pixels (0, 8)
+            const uint32_t RL = __builtin_amdgcn_alignbit(above, T[0], 16);   // T of the right neighbours of pixels (7, 15)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) P[j] = pk_min3_f16bits(P[j], j ? T[j - 1] : L0, j < 7 ? T[j + 1] : RL);
+        };
+        bool saturated = false;
+        int it = 1, next_chk = max(2, hint - 1);
+        for (; it <= EDT_W_ITMAX; ++it) {
+            cascade_step(it);
+            const bool last = it == EDT_W_ITMAX;
+            if (!last && it < next_chk) continue;
+            next_chk = it + 1 + (it >= 12 ? (it >> 3) : 0);
+            uint32_t m;
+            if (FULL) {
+                m = P[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) m = pk_max(m, P[j]);
+                m = max(m & 0xFFFFu, m >> 16);
+            } else {
+                m = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nvalid) m = max(m, P[j] & 0xFFFFu);
+                    if (j + 8 < nvalid) m = max(m, P[j] >> 16);
+                }
+            }
+            const uint32_t thr = (uint32_t)(it + 1) * (uint32_t)(it + 1);
+            if (__ballot(m > thr) == 0) break;
+            if (last) { saturated = true; break; }
+        }
+        hint = it;
+        if (!saturated) {
+            uint32_t R[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                R[m] = __builtin_amdgcn_perm(P[2 * m + 1], P[2 * m], 0x05040100u);       // pixels 2m, 2m + 1
+                R[m + 4] = __builtin_amdgcn_perm(P[2 * m + 1], P[2 * m], 0x07060302u);   // pixels 8 + 2m, 9 + 2m
+            }
+            uint32_t* wb = (lane < 32 ? tr : trb) + 8 * lane;
+            const int sw = (lane >> 2) & 1;
+            *reinterpret_cast<uint4*>(wb + 4 * sw) = make_uint4(R[0], R[1], R[2], R[3]);
+            *reinterpret_cast<uint4*>(wb + 4 * (1 - sw)) = make_uint4(R[4], R[5], R[6], R[7]);
+            wave_lds_sync();
+            // piece 64 k + lane = pixels 4 (64 k + lane) ..: owner lane 16 k + lane / 4, quarter lane % 4 of its 32 bytes
+            const int roff = 8 * (lane >> 2) + 4 * (((lane >> 1) & 1) ^ ((lane >> 4) & 1)) + 2 * (lane & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 qv = *reinterpret_cast<const uint2*>((k < 2 ? tr : trb) + roff + 128 * k);
+                const int4 v = make_int4((int)(qv.x & 0xFFFFu), (int)(qv.x >> 16), (int)(qv.y & 0xFFFFu), (int)(qv.y >> 16));
+                const int x = 4 * (64 * k + lane);
+                if (FULL || x + 3 < W) {
+                    if (FULL || (((uintptr_t)(out + x)) & 15) == 0) EDT_STORE4(out + x, v);
+                    else { out[x] = v.x; out[x + 1] = v.y; out[x + 2] = v.z; out[x + 3] = v.w; }
+                } else {
+                    if (x < W) out[x] = v.x;
+                    if (x + 1 < W) out[x + 1] = v.y;
+                    if (x + 2 < W) out[x + 2] = v.z;
+                }
+            }
+            wave_lds_sync();
+        } else {
+            // ---- 32-bit cascade with exact distances (very sparse rows: some distance beyond 175 columns) ----
+            uint32_t V[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int x = 16 * lane + j;
+                uint32_t gg = EDT_G_INF;
+                if (x < W) gg = edt_gdist_global(cb, W, nb, b, x, i);
+                V[j] = gg * gg;
+            }
+            for (int it2 = 1; it2 < WP; ++it2) {
+                const uint32_t c = (uint32_t)(2 * it2 - 1);
+                const uint32_t below = from_lane_below(V[15], (uint32_t)EDT_F_INF);
+                const uint32_t above = from_lane_above(V[0], (uint32_t)EDT_F_INF);
+                uint32_t prev = below;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t cur = V[j];
+                    const uint32_t nxt = j < 15 ? V[j + 1] : above;
+                    V[j] = min(cur, min(prev, nxt) + c);
+                    prev = cur;
+                }
+                if ((it2 & 7) == 0) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (FULL || j < nvalid) m = max(m, V[j]);
+                    const uint32_t thr = (uint32_t)(it2 + 1) * (uint32_t)(it2 + 1);
+                    if (__ballot(m > thr && (m < (uint32_t)EDT_F_INF || it2 + 1 < W)) == 0) break;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int x = 16 * lane + j;
+                if (x < W) out[x] = V[j] >= (uint32_t)EDT_F_INF ? INT32_MAX : (int)V[j];
+            }
+        }
+    }
+}
+
+template <bool FULL>
+static int launch_band_k16(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
+    const size_t lds = (size_t)32 * 1024 + 8 * 1024;
+    int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+    ctx->edt_chain_token = -1;
+    hipLaunchKernelGGL((edt_band_k16_kernel<FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream, colbits, W, H, nb, d2);
+    sc_time_end(ctx, tk);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 template <int PPL, bool FULL>
 static int launch_band_g8(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     constexpr int WP = 64 * PPL;
@@ -1215,7 +1485,10 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
     int tk = sc_time_begin(ctx, SC_K_EDT_COLBITS);
     if (skip_colbits) {
     } else if (W % 16 == 0 && ((uintptr_t)occ & 15) == 0) {
-        hipLaunchKernelGGL(edt_colbits_kernel, dim3((W + 1023) / 1024, nb, batch), dim3(64, 4), 0, ctx->stream,
+        hipLaunchKernelGGL(edt_colbits_kernel<true>, dim3((W + 1023) / 1024, nb, batch), dim3(64, 4), 0, ctx->stream,
+                           occ, W, H, nb, colbits);
+    } else if (W % 4 == 0 && ((uintptr_t)occ & 3) == 0) {
+        hipLaunchKernelGGL(edt_colbits_kernel<false>, dim3((W + 1023) / 1024, nb, batch), dim3(64, 4), 0, ctx->stream,
                            occ, W, H, nb, colbits);
     } else {
         dim3 grid((W + 255) / 256, nb, batch);
@@ -1229,7 +1502,11 @@ int sc_launch_edt(sc_ctx* ctx, const uint8_t* occ, int W, int H, int batch, int3
     if (W <= 256) return launch_band_ppl<4>(ctx, colbits, W, H, nb, batch, d2);
 #ifndef EDT_NO_G8
     if (W > 256 && W <= 512) return launch_band_g8_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
-    if (W > 512 && W <= 1024) return launch_band_g8_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
+    if (W > 512 && W <= 1024) {
+        static const bool old16 = getenv("SC_EDT_OLD16") && atoi(getenv("SC_EDT_OLD16"));   // A/B against edt_band_g8_kernel<16>
+        if (old16) return launch_band_g8_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
+        return W == 1024 ? launch_band_k16<true>(ctx, colbits, W, H, nb, batch, d2) : launch_band_k16<false>(ctx, colbits, W, H, nb, batch, d2);
+    }
 #endif
     if (W <= 512) return launch_band_ppl<8>(ctx, colbits, W, H, nb, batch, d2);
     if (W <= 1024) return launch_band_ppl<16>(ctx, colbits, W, H, nb, batch, d2);
