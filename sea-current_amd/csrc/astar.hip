@@ -297,15 +297,15 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 #define ASTAR_SPIN_LIMIT (1 << 20)   // polls (about 100 cycles each) wavefront 0 waits for wavefront 1 before it gives the query up
 template <typename GT, bool DUAL>
 __device__ __forceinline__ void astar_query(const astar_args& a, const int q, const int slot) {
-    __shared__ uint32_t qe[CQ];            // LDS ring of the current f level
+    __shared__ uint32_t qe[CQ + 64];       // LDS ring of the current f level (+ one spare word per lane: lanes with nothing to append write there)
     __shared__ int s_head[NBUCKET];        // head / tail of the 32 HBM rings: lanes that insert take their slot with one
     __shared__ int s_tail[NBUCKET];        // LDS atomic add on the tail; heads only move in wave-uniform code
     __shared__ uint32_t nd_xy[64];         // wide steps: the popped nodes (y << 16 | x) and their legal-move bytes
     __shared__ uint32_t nd_mv[64];
     __shared__ uint16_t succ[512];         // wide steps: compacted successor list (node << 3 | move)
     __shared__ uint8_t prune_tbl[64];      // entry_prune by the entry's bits 13..18 (arrival move, side flags, run flag)
-    __shared__ uint32_t dup_tbl[DUAL ? 1024 : 1];  // DUAL: the node last popped under hash (x + 32 y) mod 1024 (y << 16 | x, lane in the spare bits)
-    __shared__ uint2 hq_rec[DUAL ? HQ : 1];   // hand-over ring: (node y << 16 | x, moves | legal moves << 8)
+    __shared__ uint32_t dup_tbl[DUAL ? 1024 + 64 : 1];  // DUAL: the node last popped under hash (x + 32 y) mod 1024 (y << 16 | x, lane in the spare bits); + a spare word per lane
+    __shared__ uint2 hq_rec[DUAL ? HQ + 64 : 1];   // hand-over ring: (node y << 16 | x, moves | legal moves << 8); + a spare record per lane
     __shared__ int hq_tail, hq_head, hq_clean, hq_stop, hq_ovf, hq_fcur, hq_found, hq_flush;   // hq_fcur: the level of everything in the ring (it is empty whenever the level changes)
     constexpr int SCOPE = DUAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT;
     const int lane = threadIdx.x & 63;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     if (wv == 0 && lane < NBUCKET) { s_head[lane] = 0; s_tail[lane] = 0; }
     if (wv == 0) prune_tbl[lane] = (uint8_t)entry_prune((uint32_t)lane << 13);
     if (DUAL)
-        for (int i = threadIdx.x; i < 1024; i += 128) dup_tbl[i] = 0xFFFFFFFFu;   // no node popped yet in this search
+        for (int i = threadIdx.x; i < 1024 + 64; i += 128) dup_tbl[i] = 0xFFFFFFFFu;   // no node popped yet in this search
     int fcur = octile(sx, sy, gx, gy);
     if (wv == 0 && lane == 0) {
         qe[0] = (uint32_t)sy << 19 | E_START | (uint32_t)sx;
@@ -423,13 +423,13 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     }
                 }
             }
-            if (rec) {
+            {
                 const int r = (hq_tl + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u))) & (HQ - 1);
-                hq_rec[r] = make_uint2((uint32_t)hy << 16 | (uint32_t)hx, hm | hp << 8);
+                hq_rec[rec ? r : HQ + lane] = make_uint2((uint32_t)hy << 16 | (uint32_t)hx, hm | hp << 8);   // lanes without a record: their spare one
             }
             hq_tl += cnt;
             wave_lds_sync();
-            if (lane == 0) __hip_atomic_store(&hq_tail, hq_tl, __ATOMIC_RELAXED, SCOPE);
+            __hip_atomic_store(&hq_tail, hq_tl, __ATOMIC_RELAXED, SCOPE);   // every lane the same word and value: no EXEC juggling for one lane
         }
         return wm;
     };
@@ -444,24 +444,27 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
     // behind step t + 1's s_waitcnt vmcnt(0), which the OR of step t has completed by then (vmcnt counts atomics).
     constexpr uint32_t DUP_KEY = 0x1FFF1FFFu, DUP_EMPTY = 0xFFFFFFFFu;
     auto dup_settle = [&](const bool is, const int hx, const int hy, const uint32_t he) {
-        const int h = (hx + 32 * hy) & 1023;
+        // Lanes without a node work on a spare word of their own: the three LDS operations then run under the full EXEC mask,
+        // back to back (LDS executes a wave's operations in order: the first read sees what earlier steps left, the second
+        // what this step's writes left), with ONE wait -- no s_and_saveexec / s_or pairs and no second round trip.
+        const int h = is ? ((hx + 32 * hy) & 1023) : 1024 + lane;
         const uint32_t key = (uint32_t)hy << 16 | (uint32_t)hx;
         const uint32_t mine = key | ((uint32_t)(lane & 7) << 13) | ((uint32_t)(lane >> 3) << 29);
-        const uint32_t before = is ? dup_tbl[h] : DUP_EMPTY;                       // what earlier steps left there
-        const bool closed_before = before != DUP_EMPTY && ((before ^ key) & DUP_KEY) == 0u;
-        const bool cand = is && !closed_before;
-        if (cand) dup_tbl[h] = mine;
+        const uint32_t before = dup_tbl[h];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // compiler only: keep the order read, write, read
+        dup_tbl[h] = mine;
         wave_lds_sync();
-        const uint32_t now = cand ? dup_tbl[h] : mine;
+        const uint32_t now = dup_tbl[h];
+        const bool closed_before = is && before != DUP_EMPTY && ((before ^ key) & DUP_KEY) == 0u;
         int res = closed_before ? 1 : 0;
-        if (__ballot(now != mine)) {
-            if (now != mine) res = ((now ^ key) & DUP_KEY) == 0u ? 1 : 2;
+        if (__ballot(is && now != mine)) {
+            if (is && !closed_before && now != mine) res = ((now ^ key) & DUP_KEY) == 0u ? 1 : 2;
             const bool back = res == 2;
             const unsigned long long mb = __ballot(back);
             if (mb) {
                 const int c = __popcll(mb);
                 if (__builtin_expect(lt - lh + c <= CQ, 1)) {
-                    if (back) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))) & (CQ - 1)] = he;
+                    qe[back ? ((lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))) & (CQ - 1)) : CQ + lane] = he;
                     lt += c;
                 } else push_entry(back, he, 0);
                 npop -= c;   // they are popped again
@@ -581,7 +584,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int kl = n <= 4 ? 3 : n <= 8 ? 2 : n <= 16 ? 1 : 0, KL = 1 << kl, GL = 2 * KL;   // log2 lanes per direction; lanes per direction, per node
                 const int sub = lane >> (kl + 1), j = (lane >> kl) & 1, k = lane & (KL - 1);
                 const bool valid = sub < n;
-                const uint32_t e = valid ? qe[(lh + sub) & (CQ - 1)] : 0u;
+                const uint32_t e_raw = qe[(lh + sub) & (CQ - 1)];   // read under the full EXEC mask (the index is always inside the ring)
+                const uint32_t e = valid ? e_raw : 0u;
                 lh += n;
                 const int x = e & 0x1FFF, y = e >> 19;
                 const uint32_t bit = 1u << (x & 31);
@@ -616,7 +620,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     if (ma) {
                         const int c = __popcll(ma);
                         if (__builtin_expect(lt - lh + c <= CQ, 1)) {
-                            if (act) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u))) & (CQ - 1)] = ne;
+                            qe[act ? ((lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u))) & (CQ - 1)) : CQ + lane] = ne;
                             lt += c;
                         } else push_entry(act, ne, 0);                            // ring full: the general path parks them in the level's HBM ring
                     }
@@ -680,7 +684,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 ++nwide;
 #endif
                 const bool valid = lane < n;
-                const uint32_t e = valid ? qe[(lh + lane) & (CQ - 1)] : 0u;
+                const uint32_t e_raw = qe[(lh + lane) & (CQ - 1)];   // read under the full EXEC mask
+                const uint32_t e = valid ? e_raw : 0u;
                 lh += n;
                 const int x = e & 0x1FFF, y = e >> 19;
                 const uint32_t bit = 1u << (x & 31);
@@ -711,8 +716,8 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                     const int cD = __popcll(mD), c2 = cD + __popcll(mS);
                     if (c2) {
                         if (__builtin_expect(lt - lh + c2 <= CQ, 1)) {
-                            if (pD) qe[(lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mD >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mD, 0u))) & (CQ - 1)] = neD;
-                            if (pS) qe[(lt + cD + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mS, 0u))) & (CQ - 1)] = neS;
+                            qe[pD ? ((lt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mD >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mD, 0u))) & (CQ - 1)) : CQ + lane] = neD;
+                            qe[pS ? ((lt + cD + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mS, 0u))) & (CQ - 1)) : CQ + lane] = neS;
                             lt += c2;
                         } else {
                             push_entry(pD, neD, 0);      // ring full: the general path parks them in the level's HBM ring
