@@ -28,8 +28,8 @@
 // ::curvature, ::angular_velocity -- with these the reference's whole example pipeline (examples/zmq_test.cpp:66-93)
 // runs through this header.  bezier_spline::pts is an n x 2 matrix (Eigen's when present) as in the reference (:390).
 // The planner's sampling helpers keep their signatures as host functions (halton, sample_free, near, point_set,
-// x_state / y_state); fast_marching_trees itself plans on the grid.  Not mirrored: Q_cache (the reference's cached
-// Fourier coefficients), the ZMQ transport.  The service's request text and JSON reply are parse_path_request / serialize_path_to_json.
+// x_state / y_state); fast_marching_trees itself plans on the grid.  Q_cache (the reference's cached Fourier coefficients) is
+// kept and filled on the host; not mirrored: the ZMQ transport.  The service's request text and JSON reply are parse_path_request / serialize_path_to_json.
 //
 // Eigen and toppra are NOT required: if <Eigen/Dense> is on the include path it is used for
 // Vector2f / VectorXf, otherwise small stand-ins with the same accessors are provided.
@@ -77,6 +77,7 @@ using Eigen::VectorXf;
 using VectorXd = Eigen::VectorXd;
 template <int N> using VectorNd = Eigen::Matrix<double, N, 1>;
 using points_matrix = Eigen::Matrix<float, Eigen::Dynamic, 2>;   // bezier_spline::pts (sea_current.hpp:390)
+using fourier_matrix = Eigen::Matrix<std::complex<float>, Eigen::Dynamic, 2>;   // an entry of bezier_spline::Q_cache (:393)
 #else
 // minimal stand-ins with the accessors the API and the reference's call sites use
 struct Vector2f {
@@ -157,6 +158,17 @@ struct points_matrix {
     VectorXf col(size_t c) const { VectorXf v(rows()); for (size_t i = 0; i < rows(); ++i) v(i) = d[2 * i + c]; return v; }
     const float* data() const { return d.data(); }
     float* data() { return d.data(); }
+};
+// (degree + 1) x 2 complex coefficients: an entry of bezier_spline::Q_cache (sea_current.hpp:393)
+struct fourier_matrix {
+    std::vector<std::complex<float>> d;
+    fourier_matrix() = default;
+    explicit fourier_matrix(size_t n, size_t = 2) : d(2 * n) {}
+    static fourier_matrix Zero(size_t n, size_t = 2) { return fourier_matrix(n); }
+    size_t rows() const { return d.size() / 2; }
+    size_t cols() const { return 2; }
+    std::complex<float>& operator()(size_t i, size_t c) { return d[2 * i + c]; }
+    const std::complex<float>& operator()(size_t i, size_t c) const { return d[2 * i + c]; }
 };
 #endif
 
@@ -633,8 +645,25 @@ public:
     std::vector<std::vector<Vector2f>> ctrl_pts;  // control points per segment (degree + 1 each)
     points_matrix pts;                            // sampled points, one row each, in sample order
     std::vector<VectorXf> positions;              // per segment: the curve parameters of its samples (as :392)
-    // (the reference also caches the Fourier coefficients of its Bernstein-Fourier evaluation, Q_cache :393; curves are
-    // evaluated from the control points here, so there is nothing to cache)
+    // per segment: the inverse discrete Fourier transform of its control points, the coefficients of the reference's
+    // Bernstein-Fourier evaluation (:393, filled as :700-716 and :746 / :554-567 do).  Curves are evaluated from the control
+    // points here (on the GPU); the member is kept, and kept filled, for callers that read it.
+    std::vector<fourier_matrix> Q_cache;
+    static fourier_matrix fourier_coefficients(const std::vector<Vector2f>& cp) {
+        const size_t n = cp.size();
+        fourier_matrix Q = fourier_matrix::Zero(n, 2);
+        for (size_t k = 0; k < n; ++k) {
+            std::complex<double> ax(0, 0), ay(0, 0);
+            for (size_t j = 0; j < n; ++j) {
+                const double ang = 2.0 * 3.14159265358979323846 * (double)((j * k) % n) / (double)n;      // inverse transform: e^{+2 pi i jk / n} / n
+                const std::complex<double> w(std::cos(ang), std::sin(ang));
+                ax += (double)cp[j].x() * w; ay += (double)cp[j].y() * w;
+            }
+            Q(k, 0) = std::complex<float>((float)(ax.real() / n), (float)(ax.imag() / n));
+            Q(k, 1) = std::complex<float>((float)(ay.real() / n), (float)(ay.imag() / n));
+        }
+        return Q;
+    }
 
     bezier_spline() = default;
     bezier_spline(const std::vector<std::vector<Vector2f>>& ctrl_pts, const points_matrix& pts, const std::vector<VectorXf>& positions)
@@ -666,7 +695,9 @@ public:
         const int M = (int)positions.rows();
         std::vector<float> t(M);
         for (int i = 0; i < M; ++i) t[i] = positions(i);
-        return bezier_spline({ctrl_pts}, evaluate({ctrl_pts}, std::vector<int32_t>(M, 0), t, ctx), {positions});
+        bezier_spline bs({ctrl_pts}, evaluate({ctrl_pts}, std::vector<int32_t>(M, 0), t, ctx), {positions});
+        bs.Q_cache = {fourier_coefficients(ctrl_pts)};
+        return bs;
     }
     static bezier_spline bezier_curve(const std::vector<Vector2f>& ctrl_pts, const std::vector<float>& positions, gpu_context& ctx = default_context()) {
         VectorXf p = VectorXf::Zero(positions.size());
@@ -693,6 +724,7 @@ public:
             for (int i = 0; i < sp.n_segments(); ++i) {
                 bs.ctrl_pts.push_back(sp.ctrl_pts[i]);
                 if (i < (int)sp.positions.size()) bs.positions.push_back(sp.positions[i]);
+                bs.Q_cache.push_back(i < (int)sp.Q_cache.size() ? sp.Q_cache[i] : fourier_coefficients(sp.ctrl_pts[i]));
             }
             for (int r = 0; r < sp.n_pts(); ++r, ++o) { bs.pts(o, 0) = sp.pts(r, 0); bs.pts(o, 1) = sp.pts(r, 1); }
         }
@@ -750,6 +782,7 @@ public:
             for (int k = 0; k <= NS; ++k) { seg[(size_t)i * (NS + 1) + k] = i; t[(size_t)i * (NS + 1) + k] = p(k); }
         bs.pts = evaluate(bs.ctrl_pts, seg, t, ctx);
         bs.positions.assign(n - 1, p);
+        for (const auto& cp : bs.ctrl_pts) bs.Q_cache.push_back(fourier_coefficients(cp));
         return bs;
     }
 

@@ -125,6 +125,21 @@ int main(int argc, char** argv) {
         CHECK(kept.x() == 0.0f && kept.y() == 1.5f);
         bezier_spline pad = bezier_spline::from_path({Vector2f(0, 0), Vector2f(1.9f, 0), Vector2f(1.9f, 8)}, walled, 0.0f);
         CHECK(pad.ctrl_pts[0][1].x() <= 2.0f + 1e-6f);
+        // Q_cache (:393): per segment the inverse DFT of the control points; with omega_table the reference's Bernstein-Fourier
+        // sum  B(s) = sum_k Re(Q_k (1 + s (omega_k - 1))^degree)  (:736-743) must give the sampled points
+        CHECK(pad.Q_cache.size() == 2 && pad.Q_cache[0].rows() == 4);
+        {
+            const auto om3 = bezier_spline::omega_table(3);
+            for (int i : {0, 2500, 7000, 10000}) {
+                const float sp = pad.positions[1](i);
+                std::complex<float> bx(0, 0), by(0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    const std::complex<float> b = std::complex<float>(1, 0) + sp * (om3[k] - std::complex<float>(1, 0));
+                    bx += pad.Q_cache[1](k, 0) * (b * b * b); by += pad.Q_cache[1](k, 1) * (b * b * b);
+                }
+                CHECK(std::fabs(bx.real() - pad.pts(10001 + i, 0)) < 2e-5f && std::fabs(by.real() - pad.pts(10001 + i, 1)) < 2e-5f);
+            }
+        }
         const auto om = bezier_spline::omega_table(3);      // the 4th roots of unity, clockwise (:1096-1106)
         CHECK(om.size() == 4 && std::abs(om[0] - std::complex<float>(1, 0)) < 1e-6f && std::abs(om[1] - std::complex<float>(0, -1)) < 1e-6f &&
               std::abs(om[2] - std::complex<float>(-1, 0)) < 1e-6f);
