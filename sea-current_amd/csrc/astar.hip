@@ -1037,7 +1037,7 @@ static int astar_resident_dual(sc_ctx* ctx) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel_dual<uint8_t>, 128, 0) == hipSuccess && per_cu > 0 &&
         hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
         n = per_cu * prop.multiProcessorCount;
-    if (const char* e = getenv("SC_ASTAR_DUAL")) { if (atoi(e) == 0) n = 0; }
+    if (const char* e = getenv("SC_ASTAR_DUAL")) { const int v = atoi(e); if (v == 0) n = 0; else if (v > 1 && v < n) n = v; }   // 0 = off, N > 1 = at most N resident
     ctx->astar_dual = n;
     return n;
 }

@@ -821,7 +821,7 @@ static void launch_updown(sc_ctx* ctx, const uint32_t* colbits, int W, int nb, i
 template <int TILES, bool FULL>
 __global__ void __launch_bounds__(1024, 4)
 edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __restrict__ updown, int W, int H, int nb, int nsb, int ngroups,
-                     int32_t* __restrict__ d2, uint16_t* __restrict__ rowbuf) {
+                     int32_t* __restrict__ d2, uint16_t* __restrict__ rowbuf, int32_t* __restrict__ fault) {
     static_assert(TILES >= 2 && TILES <= 4, "rows of 1025 .. 4096 pixels");
     constexpr int RB = 16;                          // rows per group
     constexpr int NP = 8;                           // producer wavefronts
@@ -1104,7 +1104,10 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
         if (did) spin = 0;
         else {
             __builtin_amdgcn_s_sleep(8);
-            if (++spin > EDT_W_SPIN_LIMIT) break;                       // never expected; a bounded wait cannot hang the GPU
+            if (++spin > EDT_W_SPIN_LIMIT) {                            // never expected; a bounded wait cannot hang the GPU,
+                if (lane == 0) *fault = 1;                              // and sc_ctx_synchronize reports the call as failed
+                break;
+            }
         }
     }
 }
@@ -1129,9 +1132,14 @@ static int launch_band_wide(sc_ctx* ctx, const uint32_t* colbits, int W, int H, 
     {   // one row of u16 per wavefront for the rows the packed cascade gives up on
         int r_ = sc_scratch_reserve(ctx, &ctx->edt_rowbuf, (size_t)nwg * 16 * W * sizeof(uint16_t));
         if (r_ != SC_OK) return r_;
+        if (!ctx->edt_fault.p) {
+            r_ = sc_scratch_reserve(ctx, &ctx->edt_fault, sizeof(int32_t));
+            if (r_ != SC_OK) return r_;
+            SC_HIP(ctx, hipMemsetAsync(ctx->edt_fault.p, 0, sizeof(int32_t), ctx->stream));
+        }
     }
     hipLaunchKernelGGL((edt_band_wide_kernel<TILES, FULL>), dim3((unsigned)nwg), dim3(1024), lds, ctx->stream, colbits,
-                       (const uint32_t*)ctx->updown.p, W, H, nb, nsb, ngroups, d2, (uint16_t*)ctx->edt_rowbuf.p);
+                       (const uint32_t*)ctx->updown.p, W, H, nb, nsb, ngroups, d2, (uint16_t*)ctx->edt_rowbuf.p, (int32_t*)ctx->edt_fault.p);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
