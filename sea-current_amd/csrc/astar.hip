@@ -53,8 +53,19 @@
 #include <stdlib.h>
 
 #define NBUCKET 32
-#define CQ 1024         // LDS ring entries for the current-f queue (power of two)
-#define REFILL 512      // entries moved from the level's HBM ring into the LDS ring at a time
+// The LDS ring of the current f level holds CQ entries (a power of two) and is refilled from the level's HBM ring CQ / 2
+// entries at a time, RU x 64 loads under way at once.  Two builds of the two-wavefront kernel (astar_run picks):
+//   throughput  CQ 1024, RU 4: 13.1 KiB of LDS and <= 80 VGPRs, 12 searches per CU -- batches larger than the chip holds;
+//   latency     CQ 2048, RU 8: 17.2 KiB and 81 VGPRs, 9 per CU -- every search of the batch resident at once, where
+//               the call lasts as long as its longest search and a refill of a wide level is half as many round trips.
+#ifndef ASTAR_CQ_THROUGHPUT
+#define ASTAR_CQ_THROUGHPUT 1024
+#define ASTAR_RU_THROUGHPUT 4
+#endif
+#ifndef ASTAR_CQ_LATENCY
+#define ASTAR_CQ_LATENCY 2048
+#define ASTAR_RU_LATENCY 8
+#endif
 #define E_RUN (1u << 18)       // entry flag: the node's continuation in its arrival direction is already queued
 #define E_START (4u << 13 | 3u << 16)   // the start node: no parent (a diagonal arrival never has side flags)
 #define RUNK 8                 // cells of a same-f straight or diagonal run queued at once
@@ -293,10 +304,13 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 // They meet only when a level is exhausted: wavefront 0 waits until wavefront 1 has nothing left (everything for the
 // later levels is then in their rings) before it picks the next level.  No barrier per step -- the two earlier
 // multi-wavefront forms (tools/microbench/astar_*_experiment.hip.txt) lost exactly there.
+#ifndef HQ
 #define HQ 256   // records of the hand-over ring
+#endif
 #define ASTAR_SPIN_LIMIT (1 << 20)   // polls (about 100 cycles each) wavefront 0 waits for wavefront 1 before it gives the query up
-template <typename GT, bool DUAL>
+template <typename GT, bool DUAL, int CQ, int REFILL_UNROLL>
 __device__ __forceinline__ void astar_query(const astar_args& a, const int q, const int slot) {
+    constexpr int REFILL = CQ / 2;         // entries moved from the level's HBM ring into the LDS ring at a time
     __shared__ uint32_t qe[CQ + 64];       // LDS ring of the current f level (+ one spare word per lane: lanes with nothing to append write there)
     __shared__ int s_head[NBUCKET];        // head / tail of the 32 HBM rings: lanes that insert take their slot with one
     __shared__ int s_tail[NBUCKET];        // LDS atomic add on the tail; heads only move in wave-uniform code
@@ -567,7 +581,17 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail[b], __ATOMIC_RELAXED, SCOPE));
                 if (hd == tl) break;
                 const int n = min(tl - hd, REFILL);
-                for (int i = lane; i < n; i += 64) qe[(lt + i) & (CQ - 1)] = bq[(hd + i) & capm];
+                // REFILL_UNROLL loads under way before the first is waited for (one after the other, a chunk of 512 entries
+                // was eight dependent round trips)
+                for (int base = lane; base < n; base += 64 * REFILL_UNROLL) {
+                    uint32_t chunk[REFILL_UNROLL];
+#pragma unroll
+                    for (int k = 0; k < REFILL_UNROLL; ++k)
+                        if (base + 64 * k < n) chunk[k] = bq[(hd + base + 64 * k) & capm];
+#pragma unroll
+                    for (int k = 0; k < REFILL_UNROLL; ++k)
+                        if (base + 64 * k < n) qe[(lt + base + 64 * k) & (CQ - 1)] = chunk[k];
+                }
                 lt += n;
                 if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, SCOPE);
                 wave_lds_sync();
@@ -952,12 +976,12 @@ __global__ void __launch_bounds__(64) astar_kernel(astar_args a) {
         // queue loop); the queue position is the counter in units of a wavefront
         const int qi = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, 1)) >> 6;
         if (qi >= nq) break;
-        astar_query<GT, false>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+        astar_query<GT, false, ASTAR_CQ_THROUGHPUT, ASTAR_RU_THROUGHPUT>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
     }
 }
 
 // Two wavefronts per query (see astar_query): for batches that leave the chip room for them.
-template <typename GT>
+template <typename GT, int CQ, int RU>
 __global__ void __launch_bounds__(128) astar_kernel_dual(astar_args a) {
     __shared__ int s_qi;
     const int nq = a.nq_dev ? *a.nq_dev : a.nq;
@@ -967,7 +991,7 @@ __global__ void __launch_bounds__(128) astar_kernel_dual(astar_args a) {
         const int qi = __builtin_amdgcn_readfirstlane(s_qi);
         __syncthreads();
         if (qi >= nq) break;
-        astar_query<GT, true>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
+        astar_query<GT, true, CQ, RU>(a, a.order ? a.order[qi] : qi, (int)blockIdx.x);
         __syncthreads();
     }
 }
@@ -1029,16 +1053,19 @@ static int astar_resident_waves(sc_ctx* ctx) {
     ctx->astar_waves = w;
     return w;
 }
-// Queries the two-wavefront kernel keeps resident (blocks of 128 threads); 0 = switched off (SC_ASTAR_DUAL=0)
-static int astar_resident_dual(sc_ctx* ctx) {
-    if (ctx->astar_dual >= 0) return ctx->astar_dual;
+// Queries a build of the two-wavefront kernel keeps resident (blocks of 128 threads); 0 = switched off (SC_ASTAR_DUAL=0)
+static int astar_resident_dual(sc_ctx* ctx, bool latency) {
+    int& cached = latency ? ctx->astar_dual_lat : ctx->astar_dual;
+    if (cached >= 0) return cached;
     int per_cu = 0, n = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel_dual<uint8_t>, 128, 0) == hipSuccess && per_cu > 0 &&
-        hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+    const hipError_t e_ = latency ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel_dual<uint8_t, ASTAR_CQ_LATENCY, ASTAR_RU_LATENCY>, 128, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, astar_kernel_dual<uint8_t, ASTAR_CQ_THROUGHPUT, ASTAR_RU_THROUGHPUT>, 128, 0);
+    if (e_ == hipSuccess && per_cu > 0 && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
         n = per_cu * prop.multiProcessorCount;
     if (const char* e = getenv("SC_ASTAR_DUAL")) { const int v = atoi(e); if (v == 0) n = 0; else if (v > 1 && v < n) n = v; }   // 0 = off, N > 1 = at most N resident
-    ctx->astar_dual = n;
+    if (latency) { if (const char* e = getenv("SC_ASTAR_LATENCY")) { if (atoi(e) == 0) n = 0; } }   // SC_ASTAR_LATENCY=0: the throughput build for every batch
+    cached = n;
     return n;
 }
 
@@ -1076,7 +1103,11 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
     size_t slots = ctx->astar_slot_budget / per_slot;
     // Two wavefronts per query (astar_kernel_dual) for every batch: it wins on one call's time (its longest search is
     // shorter) and on the saturated rate (fewer instructions per expansion); SC_ASTAR_DUAL=0 selects the one-wavefront kernel.
-    const size_t rdual = (size_t)astar_resident_dual(ctx);
+    // Batches that fit the chip whole run the latency build (every search resident at once: the call lasts as long as
+    // its longest search), larger ones the throughput build (more searches per CU).
+    const size_t rlat = (size_t)astar_resident_dual(ctx, true);
+    const bool latency = !full_g && rlat > 0 && (size_t)Q <= rlat && (size_t)Q <= slots;
+    const size_t rdual = latency ? rlat : (size_t)astar_resident_dual(ctx, false);
     const bool dual = !full_g && rdual > 0;
     const size_t resident = dual ? rdual : (size_t)astar_resident_waves(ctx);
     if (slots > resident) slots = resident;
@@ -1117,7 +1148,10 @@ static int astar_run(sc_ctx* ctx, const int32_t* d2, int G, const int32_t* qgrid
                  cost, status, ctx->gslots.p, (uint32_t*)ctx->closed.p, (uint32_t*)ctx->buckets.p, cap, expanded, ctr,
                  ovf_list, ctr + 1, ctr + 4, Q, (dual && (size_t)Q > slots) ? 1 : 0, tw, bw, gcells, bwords};
     if (full_g) hipLaunchKernelGGL(astar_kernel<uint32_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
-    else if (dual) hipLaunchKernelGGL(astar_kernel_dual<uint8_t>, dim3((unsigned)slots), dim3(128), 0, ctx->stream, a);
+    else if (dual && latency && (size_t)Q <= slots)
+        hipLaunchKernelGGL((astar_kernel_dual<uint8_t, ASTAR_CQ_LATENCY, ASTAR_RU_LATENCY>), dim3((unsigned)slots), dim3(128), 0, ctx->stream, a);
+    else if (dual)
+        hipLaunchKernelGGL((astar_kernel_dual<uint8_t, ASTAR_CQ_THROUGHPUT, ASTAR_RU_THROUGHPUT>), dim3((unsigned)slots), dim3(128), 0, ctx->stream, a);
     else hipLaunchKernelGGL(astar_kernel<uint8_t>, dim3((unsigned)slots), dim3(64), 0, ctx->stream, a);
     // retry pass over the overflow list (normally empty: the wavefronts read the count and leave)
     {

@@ -59,6 +59,7 @@ struct sc_ctx {
     int cu_count = 0;               // compute units of the device (0: not asked yet)
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
     int astar_dual = -1;   // queries the two-wavefront A* kernel keeps resident (-1: not asked yet, 0: off)
+    int astar_dual_lat = -1;   // the same for its latency build (larger LDS ring: fewer per CU)
 };
 
 #define SC_HIP(ctx, call)                                                                  \

@@ -209,6 +209,20 @@ def test_astar_full_headline_batch(ctx, oracle):
     ref = oracle.astar_batch(d2h, s, g, Lmax=4096, nthreads=16)
     _compare({k: v.cpu().numpy() for k, v in out.items()}, ref, 1024)
     assert np.array_equal(ex, ref["expanded"])
+    # the same batch through the throughput build of the two-wavefront kernel (what batches larger than the chip run)
+    import os
+    import sea_current_amd as sc
+    os.environ["SC_ASTAR_LATENCY"] = "0"
+    try:
+        c2 = sc.Context(0)
+        out2 = c2.astar_batch(d2, torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda(), Lmax=4096)
+        c2.synchronize()
+        ex2 = c2.astar_debug_stats(1024)[0]
+        _compare({k: v.cpu().numpy() for k, v in out2.items()}, ref, 1024)
+        assert np.array_equal(ex2, ref["expanded"])
+        c2.close()
+    finally:
+        del os.environ["SC_ASTAR_LATENCY"]
 
 
 def test_astar_scratch_fits_what_the_device_has_free(oracle):

@@ -4,7 +4,7 @@ set -e -o pipefail
 O=gpurun_out/r3ab; mkdir -p $O
 timeout -k 10 600 python3 -m pytest tests/test_gpu_astar.py tests/test_gpu_stress.py tests/test_gpu_replan.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -30 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
-for dual in 99999 3072 2304 2048; do
+for dual in ${DUALS:-99999 3072}; do
   for rep in 1 2; do
     SC_ASTAR_DUAL=$dual timeout -k 10 300 python3 bench.py --no-cpu-baseline --only-main-map --replan-frames 0 > $O/b_${dual}_$rep.json 2> $O/b_${dual}_$rep.err
     python3 - $O/b_${dual}_$rep.json "$dual" <<'PY'

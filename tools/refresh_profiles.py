@@ -110,12 +110,12 @@ lg["note"] = ("one query, two wavefronts, alone on the chip: cycles_per_step is 
 json.dump(lg, open(os.path.join(dst, f"{tag}_astar_longest_query_pmc.json"), "w"), indent=1)
 print("A* longest:", json.dumps({k: lg[k] for k in ("ms_alone", "steps", "cycles_per_step", "per_step_both_wavefronts")}, indent=1))
 
-# ---- A* at saturation: 4096 copies of one query in one launch ----
+# ---- A* at saturation: 6144 copies of one query in one launch ----
 log = open(os.path.join(src, "astar_FETCH_SIZE.log")).read()
-m = re.search(r"x4096: ([\d.]+) ms, (\d+) expansions / (\d+) popped / (\d+) steps each -> ([\d.]+) G", log)
+m = re.search(r"x6144: ([\d.]+) ms, (\d+) expansions / (\d+) popped / (\d+) steps each -> ([\d.]+) G", log)
 ms, ex, pop, steps, gexp = float(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
-copies = 4096
-astar = {"workload": "4096 copies of one salt20 query (tools/astar_saturation.py salt20 4096) in one launch of astar_kernel_dual (2048 resident slots of two wavefronts: two rounds, no tail); per_step = per frontier step of wavefront 0, both wavefronts' instructions counted",
+copies = 6144
+astar = {"workload": "6144 copies of one salt20 query (tools/astar_saturation.py salt20 6144) in one launch of the throughput build of astar_kernel_dual (3072 resident slots of two wavefronts: two rounds, no tail); per_step = per frontier step of wavefront 0, both wavefronts' instructions counted",
          "expansions_per_query": ex, "popped_per_query": pop, "steps_per_query": steps, "launch_ms_under_profiler": ms,
          "G_expansions_per_s_under_profiler": gexp}
 

@@ -37,7 +37,7 @@ for cfg in "1024 64 blocks" "4096 4 blocks" "1024 64 salt20" "4096 4 salt20"; do
     done
     echo edt pmc $cfg done
 done
-AST="python3 $R/tools/astar_saturation.py salt20 4096"
+AST="python3 $R/tools/astar_saturation.py salt20 6144"
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCC_ATOMIC_sum" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
     tag=$(echo $grp | tr ' ' '_')
     timeout -k 5 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/astar_$tag -o a -- $AST > $O/astar_$tag.log 2>&1
