@@ -377,7 +377,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
     long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = t_begin;
-    int nwide = 0, nrounds = 0, n_qfull = 0, n_lvl = 0, b_batches = 0, b_records = 0, b_idle = 0;
+    int nwide = 0, nrounds = 0, n_qfull = 0, n_lvl = 0, b_batches = 0, b_records = 0, b_idle = 0, n_refill = 0;
 #endif
     // Every step pops at least one entry and a search pushes at most 8 entries per cell: a bound that a correct search
     // cannot reach.  It bounds wavefront 0's pop loop; its two waits on wavefront 1 (a full hand-over ring, the end of a
@@ -576,6 +576,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         // drain everything with f == fcur: the LDS ring, refilled from what earlier levels left in HBM
         for (;;) {
             if (__builtin_expect(lt == lh, 0)) {
+                STAMP(0);   // loop overhead
                 wave_lds_sync();
                 const int hd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head[b], __ATOMIC_RELAXED, SCOPE));
                 const int tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail[b], __ATOMIC_RELAXED, SCOPE));
@@ -595,6 +596,10 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
                 lt += n;
                 if (lane == 0) __hip_atomic_store(&s_head[b], hd + n, __ATOMIC_RELAXED, SCOPE);
                 wave_lds_sync();
+                STAMP(10);  // refills
+#ifdef ASTAR_STAMPS
+                ++n_refill;
+#endif
             }
             const int n = min(64, lt - lh);
             npop += n; ++nstep;
@@ -958,7 +963,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
 #ifdef ASTAR_STAMPS
     if (lane == 0 && wv == 0 && a.Lmax >= 16) {
         for (int i = 0; i < 12; ++i) path[i] = (int)(stamp[i] >> 10);
-        path[12] = nwide; path[13] = nrounds; path[14] = n_qfull; path[15] = n_lvl;
+        path[12] = nwide; path[13] = nrounds; path[14] = n_qfull; path[15] = n_lvl; path[19] = n_refill;
     }
 #endif
     }   // search
