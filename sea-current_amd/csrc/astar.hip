@@ -912,34 +912,47 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
         out_st = SC_Q_NO_PATH;
     } else {
         // ---- canonical parent chain, goal -> start, written right-aligned then shifted left ----
+        STAMP(9);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every g store of this wave has reached L2
         const int Lmax = a.Lmax;
         int cx = gx, cy = gy, L = 1;
         uint32_t gc = (uint32_t)fcur;  // g(goal) = C*
         if (lane == 0) path[Lmax - 1] = t;
         bool broken = false;
+        // One round trip fetches the legal moves, the closed bit and g of the 7 x 7 cells around the current cell (lane
+        // l < 49: cell (l % 7 - 3, l / 7 - 3)); the next three parents are then found from registers (the candidates of
+        // move d sit in lane d, which pulls its cell's data with ds_bpermute) -- not two dependent round trips per cell.
+        const int wox = lane % 7 - 3, woy = lane / 7 - 3;
+        const int md = lane & 7;
+        const int mdx_ = (int)((0x2252u >> (2 * md)) & 3u) - 1, mdy_ = (int)((0x0A25u >> (2 * md)) & 3u) - 1;
+        const uint32_t mw_ = md < 4 ? 10u : 14u;
         while (!broken && (cx != sx || cy != sy)) {
-            bool ok = false;
-            if (lane < 8) {
-                const int d = lane;
-                const int nx = cx - ddx[d], ny = cy - ddy[d];
-                if (nx >= 0 && ny >= 0 && nx < W && ny < H) {
-                    const int n = ny * W + nx;
-                    if ((mvs[n] >> d) & 1) {
-                        const uint32_t cw = g_load(&cl[cix(nx, ny, bw)]);
-                        const GT gn = g_load(&g[gidx<GT>(nx, ny, tw)]);
-                        ok = ((cw >> (nx & 31)) & 1u) && gn == (GT)(gc - (d < 4 ? 10u : 14u));  // closed in this search and g[n] + w == g[c]
-                    }
+            uint32_t info = 0u, gw = 0u;   // legal moves | closed << 8 (0 outside the grid), g
+            {
+                const int nx = cx + wox, ny = cy + woy;
+                if (lane < 49 && nx >= 0 && ny >= 0 && nx < W && ny < H) {
+                    const uint32_t mvb = mvs[ny * W + nx];
+                    const uint32_t cw = g_load(&cl[cix(nx, ny, bw)]);
+                    gw = (uint32_t)g_load(&g[gidx<GT>(nx, ny, tw)]);
+                    info = mvb | ((cw >> (nx & 31)) & 1u) << 8;
                 }
             }
-            const unsigned long long m = __ballot(ok);
-            if (!m) broken = true;
-            else {
-                const int d = __ffsll((long long)m) - 1;
-                cx -= ddx[d]; cy -= ddy[d];
-                gc -= (d < 4 ? 10u : 14u);
-                ++L;
-                if (lane == 0 && L <= Lmax) path[Lmax - L] = cy * W + cx;
+            int ox = 0, oy = 0;     // the current cell inside the window
+            for (int k = 0; k < 3 && !broken && (cx != sx || cy != sy); ++k) {
+                const int src = (oy - mdy_ + 3) * 7 + (ox - mdx_ + 3);           // the cell move md arrives from
+                const uint32_t ni = (uint32_t)__shfl((int)info, src, 64), ng = (uint32_t)__shfl((int)gw, src, 64);
+                // closed in this search, the move legal from there, and g[n] + w == g[c]
+                const bool ok = lane < 8 && ((ni >> md) & 1u) && ((ni >> 8) & 1u) && (GT)ng == (GT)(gc - mw_);
+                const unsigned long long m = __ballot(ok);
+                if (!m) broken = true;
+                else {
+                    const int d = __ffsll((long long)m) - 1;
+                    cx -= ddx[d]; cy -= ddy[d];
+                    ox -= ddx[d]; oy -= ddy[d];
+                    gc -= (d < 4 ? 10u : 14u);
+                    ++L;
+                    if (lane == 0 && L <= Lmax) path[Lmax - L] = cy * W + cx;
+                }
             }
         }
         if (broken) out_st = SC_Q_NO_PATH;
@@ -958,6 +971,7 @@ __device__ __forceinline__ void astar_query(const astar_args& a, const int q, co
             }
             out_len = L; out_cost = fcur;
         }
+        STAMP(11);  // path extraction
     }
     kcyc = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 #ifdef ASTAR_STAMPS
