@@ -14,3 +14,7 @@ print("%-10s value %.0f (%.0f..%.0f) depth1 %.0f kcyc_max %s" % (sys.argv[2], d[
 PY
   done
 done
+for lib in base $(ls sea-current_amd/variants/*.so 2>/dev/null); do
+  if [ $lib = base ]; then unset SC_LIB_PATH; else export SC_LIB_PATH=$PWD/$lib; fi
+  echo "$(basename $lib .so): $(timeout -k 10 120 python3 tools/astar_saturation.py salt20 6144 2>&1 | tail -1)"
+done
