@@ -545,6 +545,53 @@ def main():
         assert ok4, "config3: gathered paths differ from the call's own results"
         del occ4, d4, o4, ga4, msg4
 
+    # ---- what follows the planner in the reference (examples/zmq_test.cpp:66-93), batched: SURVEY 8f rows 1-2 ----
+    # the step's own A* paths -> 16 waypoints each -> from_path -> arclength -> TOPP-RA along the arclength -> sampling at
+    # 20 ms -> resample (nudge) + curvature; reported beside the headline, not part of `value`
+    if rank == 0 and world == 1 and not args.only_main_map:
+        from sea_current_amd import pipeline
+        ln_h = out["len"].cpu().numpy()
+        sel = (st == 0) & (ln_h >= 64)
+        wp_h = pipeline.waypoints_from_cells(out["path"].cpu().numpy()[sel], ln_h[sel], W, n_wp=16, cell_m=0.05)
+        wp_d = torch.from_numpy(wp_h).to(dev)
+        sm = pipeline.smooth_batch(ctx, wp_d)                    # warm-up; fixes the samples reserved per path
+        ctx.synchronize()
+        ctx.reset_timing(); ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sm = pipeline.smooth_batch(ctx, wp_d, max_len=sm["max_len"])
+        ctx.synchronize()
+        t_sm = (time.perf_counter() - t0) / 5
+        stage_ms = {name: ctx.get_timing(kid)[0] / 5 for name, kid in (("from_path", sc.K_BEZIER), ("arclength", sc.K_ARCLENGTH), ("toppra", sc.K_TOPPRA),
+                                                                        ("sampling", sc.K_TOPPRA_SAMPLE), ("resample", sc.K_RESAMPLE))}
+        ctx.set_timing(False)
+        Psm, Msm = int(wp_h.shape[0]), int(sm["pos"].shape[0])
+        # algorithmic bytes: waypoints in; control points, arclength tables, profile knots, then 9 float32 per sample out
+        # (pos, vel, acc, point x / y, parameter, segment, curvature, + the nudged position read back)
+        sm_bytes = Psm * (16 * 8 + 15 * (32 + 404) + 101 * 16) + Msm * 36
+        result["smoothing"] = {"workload": f"{Psm} of the step's A* paths (found, >= 64 cells), 16 waypoints each (0.05 m cells): from_path -> arclength (GL-32, 100 "
+                                           "subdivisions per segment) -> TOPP-RA along the arclength (1 dof, 100 stages, v <= 1 m/s, |a| <= 0.5 m/s^2) -> sampling at "
+                                           "20 ms -> resample with nudge (degree-9 Chebyshev fit per segment) + curvature",
+                               "paths": Psm, "samples": Msm, "ms_per_batch": t_sm * 1e3, "paths_per_s": Psm / t_sm, "samples_per_s": Msm / t_sm,
+                               "ms_kernels": stage_ms, "ms_kernels_sum": sum(stage_ms.values()),
+                               "algorithmic_GBps": sm_bytes / (sum(stage_ms.values()) * 1e-3) / 1e9,
+                               "hbm_frac": sm_bytes / (sum(stage_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "resample_ok": int((sm["resample_status"] == 0).sum()), "toppra_ok": int((sm["toppra_status"] == 0).sum()),
+                               "note": "ms_per_batch is host wall time for the five library calls and the torch bookkeeping between them; fp64 / fp32 as the reference; "
+                                       "bound by the dependent chains inside a path (TOPP-RA sweeps, the nudge replay, the fit), not by HBM"}
+        if not args.no_cpu_baseline:
+            from oracle import oracle  # checker / baseline only
+            oracle.build()
+            t0 = time.perf_counter()
+            refs = [oracle.smooth_one(wp_h[b]) for b in range(min(32, Psm))]
+            t_c = time.perf_counter() - t0
+            offs, lens_g = sm["offsets"].cpu().numpy(), sm["length"].cpu().numpy()
+            pts_g = sm["pts"].cpu().numpy()
+            okp = all(abs(int(lens_g[b]) - r["length"]) <= 1 and (int(lens_g[b]) != r["length"] or float(np.abs(pts_g[offs[b]:offs[b + 1]] - r["pts"]).max()) < 2e-4)
+                      for b, r in enumerate(refs))
+            result["smoothing"]["cpu"] = {"paths_per_s": len(refs) / t_c, "cores": 1, "kind": "port", "sample": f"the first {len(refs)} paths of the batch",
+                                          "gpu_matches_cpu_on_sample": bool(okp)}
+
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only, never the measured product

@@ -261,3 +261,22 @@ def fmt_star(samples, start, goal, rn, lines, Lmax=256):
            C.c_float(goal[1]), C.c_float(rn), _p(lines, C.c_float), C.c_int(lines.shape[0]), C.c_int(Lmax), _p(path, C.c_float),
            C.byref(ln), C.byref(cost))
     return dict(status=st, len=ln.value, cost=cost.value, path=path[:min(ln.value, Lmax)])
+
+
+def smooth_one(wp, vmax=1.0, amax=0.5, dt=0.02, N=100, nsub=100):
+    """The reference's post-planner sequence for ONE path (examples/zmq_test.cpp:66-93): from_path -> arclength ->
+    gen_vel_prof<1> along the arclength (TOPP-RA + sampling) -> resample(nudge) -> curvature; wp float32 [n, 2]."""
+    c = bezier_from_path(wp)
+    tot, cum = bezier_arclength(c, nsub)
+    cum = cum.astype(np.float32)
+    AL = np.float32(0.0)
+    for v in cum[:, -1]:
+        AL = np.float32(AL + v)
+    r = toppra([0.0], [float(AL)], [0.0], [0.0], [-vmax], [vmax], [-amax], [amax], N=N)
+    s = toppra_sample([0.0], [float(AL)], [0.0], [0.0], r["x"], r["t"], float(np.float32(dt)))
+    L = int(s["length"])
+    pos = s["pos"][0, :L].astype(np.float32).copy()
+    vel = s["vel"][0, :L].astype(np.float32)
+    rs = bezier_resample(c, cum, AL, pos, True)
+    return dict(ctrl=c, arclength=AL, length=L, pos=rs["pos"], vel=vel, pts=rs["pts"], curvature=rs["curvature"], seg=rs["seg"],
+                status=int(rs["status"]), toppra_status=int(r["status"]))

@@ -13,6 +13,8 @@
 #include "sc_internal.h"
 
 #include <cmath>
+#include <utility>
+#include <stdlib.h>
 
 struct seg4 { float lx0, ly0, lx1, ly1; };
 
@@ -166,13 +168,15 @@ bezier_arclength_kernel(const float* __restrict__ ctrl, int S, int nsub, const d
 // samples are checked in parallel; a chunk with a sample to fix is replayed in order by lane 0, which keeps the
 // sequential semantics exactly) and the split of the samples over the segments (first sample past the end of a
 // segment's table, found by ballot).  seginfo [S] = (first sample, last sample, spline, segment within spline).
+#define RESAMPLE_STAGE_MAX 12288      // profile samples of a spline staged in LDS (48 KiB); longer profiles are scanned in HBM
 __global__ void __launch_bounds__(64)
 resample_prepare_kernel(const float* __restrict__ cum, const int32_t* __restrict__ seg_off, int nsub, const float* __restrict__ arclen,
                         float* pp_all, const int32_t* __restrict__ prof_off, int nudge, int4* __restrict__ seginfo,
                         int32_t* __restrict__ status) {
+    extern __shared__ float spp[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int s0 = seg_off[b], nseg = seg_off[b + 1] - s0;
-    float* pp = pp_all + prof_off[b];
+    float* gpp = pp_all + prof_off[b];
     const int n = prof_off[b + 1] - prof_off[b];
     if (n <= 0 || nseg <= 0) {
         if (lane == 0) status[b] = 1;
@@ -180,54 +184,74 @@ resample_prepare_kernel(const float* __restrict__ cum, const int32_t* __restrict
         return;
     }
     const float AL = arclen[b];
-    if (nudge) {
-        if (lane == 0) { pp[0] = 0.f; pp[n - 1] = AL; }
-        __threadfence();
+    // The scans below touch every sample a few times, 64 at a time, each time waiting for the loads: from HBM that was a
+    // microsecond per step (116 us for the bench's 1500-sample profiles).  The profile is staged in LDS once, coalesced;
+    // the nudge's corrections go to both copies.
+    const bool staged = n <= RESAMPLE_STAGE_MAX;
+    if (staged) {
+        for (int i = lane; i < n; i += 64) spp[i] = gpp[i];
         __syncthreads();
-        for (int base = 1; base < n - 1; base += 64) {
-            const int i = base + lane;
-            bool fix = false;
-            if (i < n - 1) {
-                const float a = pp[i - 1], v = pp[i], c = pp[i + 1];
-                fix = v < a || v > c || v < 0.f || v > AL;
-            }
-            if (__ballot(fix) == 0ull) continue;
-            if (lane == 0) {
-                const int e = min(base + 64, n - 1);
-                for (int k = base; k < e; ++k) {
-                    float v = pp[k];
-                    if (v < pp[k - 1] || v > pp[k + 1]) v = (pp[k - 1] + pp[k + 1]) / 2;
-                    if (v < 0.f) v = 0.f;
-                    if (v > AL) v = AL;
-                    pp[k] = v;
+    }
+    // the body once per address space (a pointer that may be either compiles to flat loads that wait for every store)
+    // One wavefront per spline: lane 0's corrections have to be ordered before the other lanes' later reads, nothing more.
+    // (__threadfence() is an agent-scope fence: on gfx950 it writes the L2 back and invalidates it -- 40 us a time here.)
+    auto wave_order = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+    auto body = [&](float* const pp, const bool mirror) {
+        if (nudge) {
+            if (lane == 0) { pp[0] = 0.f; pp[n - 1] = AL; if (mirror) { gpp[0] = 0.f; gpp[n - 1] = AL; } }
+            wave_order();
+            for (int base = 1; base < n - 1; base += 64) {
+                const int i = base + lane;
+                bool fix = false;
+                if (i < n - 1) {
+                    const float a = pp[i - 1], v = pp[i], c = pp[i + 1];
+                    fix = v < a || v > c || v < 0.f || v > AL;
                 }
+                if (__ballot(fix) == 0ull) continue;
+                if (lane == 0) {
+                    // in order, as the reference does it: sample k against its already corrected predecessor (carried in a
+                    // register) and its not yet visited successor
+                    const int e = min(base + 64, n - 1);
+                    float prev = pp[base - 1], cur = pp[base];
+                    for (int k = base; k < e; ++k) {
+                        const float nxt = pp[k + 1];
+                        float v = cur;
+                        if (v < prev || v > nxt) v = (prev + nxt) / 2;
+                        if (v < 0.f) v = 0.f;
+                        if (v > AL) v = AL;
+                        pp[k] = v;
+                        if (mirror) gpp[k] = v;
+                        prev = v; cur = nxt;
+                    }
+                }
+                wave_order();
             }
-            __threadfence();
-            __syncthreads();
         }
-    }
-    const int m = nsub + 1;
-    int j = 0, st = 0;
-    float offset = 0.f;
-    for (int i = 0; i < nseg; ++i) {
-        const float last = cum[(size_t)(s0 + i) * m + m - 1];
-        const int start = j;
-        while (j < n) {
-            const int k = j + lane;
-            const bool past = k >= n || !(pp[k] - offset <= last);
-            const unsigned long long bal = __ballot(past);
-            if (bal) { j += __ffsll((long long)bal) - 1; break; }
-            j += 64;
+        const int m = nsub + 1;
+        int j = 0, st = 0;
+        float offset = 0.f;
+        for (int i = 0; i < nseg; ++i) {
+            const float last = cum[(size_t)(s0 + i) * m + m - 1];
+            const int start = j;
+            while (j < n) {
+                const int k = j + lane;
+                const bool past = k >= n || !(pp[k] - offset <= last);
+                const unsigned long long bal = __ballot(past);
+                if (bal) { j += __ffsll((long long)bal) - 1; break; }
+                j += 64;
+            }
+            if (j > n) j = n;
+            if (i + 1 == nseg && i == 0) j = n;
+            else if (i + 1 == nseg) j = n - 1;
+            j -= 1;
+            if (j < start) { st = 1; j = start; }
+            offset = pp[j];
+            if (lane == 0) seginfo[s0 + i] = make_int4(start, j, b, i);
         }
-        if (j > n) j = n;
-        if (i + 1 == nseg && i == 0) j = n;
-        else if (i + 1 == nseg) j = n - 1;
-        j -= 1;
-        if (j < start) { st = 1; j = start; }
-        offset = pp[j];
-        if (lane == 0) seginfo[s0 + i] = make_int4(start, j, b, i);
-    }
-    if (lane == 0) status[b] = st;
+        if (lane == 0) status[b] = st;
+    };
+    if (staged) body(spp, true);
+    else body(gpp, false);
 }
 
 
@@ -307,6 +331,170 @@ resample_eval_kernel(const float* __restrict__ ctrl, const float* __restrict__ c
         double t0 = 1, t1 = xn, y = coef[0];
         if (deg > 1) y += coef[1] * t1;
         for (int j = 2; j < deg; ++j) { const double t2 = 2 * xn * t1 - t0; y += coef[j] * t2; t0 = t1; t1 = t2; }
+        float t = (float)y;
+        if (t < 0.f) t = 0.f;
+        if (t > 1.f) t = 1.f;
+        const size_t og = (size_t)p0 + o;
+        double px, py;
+        bez_eval(c, (double)t, 0, px, py);
+        if (pts) { pts[2 * og] = (float)px; pts[2 * og + 1] = (float)py; }
+        if (tpar) tpar[og] = t;
+        if (seg) seg[og] = il;
+        if (curv) {
+            double ax, ay, bx, by;
+            bez_eval(c, (double)t, 1, ax, ay);
+            bez_eval(c, (double)t, 2, bx, by);
+            curv[og] = (float)((ax * by - ay * bx) / pow(ax * ax + ay * ay, 1.5));
+        }
+    }
+}
+
+// Kernel 2 in registers, one WAVEFRONT per segment, for tables of 10 .. 64 RPL rows (nsub = 100: RPL 2): the [T | y] matrix
+// lives in the lanes' registers (row r in lane r % 64, slot r / 64; rows past the table are zero and stay zero), a dot product
+// over the rows is a DPP reduction (quad_perm, row_half_mirror, row_mirror, row_bcast 15 / 31: no LDS, no barrier), and the
+// pivot row k is lane k's slot 0, read with v_readlane.  The Householder steps of the LDS form above, column k against all the
+// columns to its right at once (their dot products are reduced together; 2 / v'v is formed once per column) --
+// which spent 86 us per segment on 55 (k, j) pairs of LDS passes and shuffles by one wavefront of four (630 us for the
+// bench's 15 k segments); the sums over rows are grouped differently (fp64: 1e-16 relative).
+template <int CTRL, int ROW_MASK, bool ALL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    // ALL: every lane has a source lane (the permutations inside a row); otherwise lanes the row mask leaves out read 0
+    const long long b = __double_as_longlong(v);
+    int lo, hi;
+    if (ALL) {
+        lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// the sums over the 64 lanes of N values at once (step by step over all of them: the N chains are independent, so no
+// DPP wait states and no dependent adds back to back); the same totals in every lane
+template <int N>
+__device__ __forceinline__ void wave_sum_dpp(double (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0xB1, 0xF, true>(v[j]);     // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0x4E, 0xF, true>(v[j]);     // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0x141, 0xF, true>(v[j]);    // row_half_mirror
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0x140, 0xF, true>(v[j]);    // row_mirror: every lane of a row of 16 holds the row's sum
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0x142, 0xA, false>(v[j]);   // row_bcast 15 into rows 1 and 3
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += dpp_f64<0x143, 0xC, false>(v[j]);   // row_bcast 31 into rows 2 and 3: lane 63 holds the total
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = readlane_f64(v[j], 63);
+}
+
+// Householder step of column K of the [T | y] matrix in registers (rows: lane + 64 slot), against all the columns to its right
+template <int K, int RPL>
+__device__ __forceinline__ void hh_col(double (&a)[RPL][11], const int lane) {
+    constexpr int NC = 11;
+    double part[1] = {lane >= K ? a[0][K] * a[0][K] : 0.0};
+#pragma unroll
+    for (int i = 1; i < RPL; ++i) part[0] += a[i][K] * a[i][K];
+    wave_sum_dpp<1>(part);
+    const double nrm = sqrt(part[0]);
+    if (nrm == 0) return;                                     // wave-uniform
+    const double akk = readlane_f64(a[0][K], K), alpha = akk > 0 ? -nrm : nrm;
+    const double vk = akk - alpha, vtv = nrm * nrm - akk * akk + vk * vk;
+    const double tvv = 2 / vtv;
+    double d[NC - 1 - K];                                     // the dot products of column K with every column to its right
+#pragma unroll
+    for (int j = K + 1; j < NC; ++j) {
+        double t = lane > K ? a[0][K] * a[0][j] : 0.0;
+#pragma unroll
+        for (int i = 1; i < RPL; ++i) t += a[i][K] * a[i][j];
+        d[j - K - 1] = t;
+    }
+    wave_sum_dpp<NC - 1 - K>(d);                              // reduced together
+#pragma unroll
+    for (int j = K + 1; j < NC; ++j) {
+        const double f = (d[j - K - 1] + vk * readlane_f64(a[0][j], K)) * tvv;
+        if (lane > K) a[0][j] -= f * a[0][K];
+        else if (lane == K) a[0][j] -= f * vk;
+#pragma unroll
+        for (int i = 1; i < RPL; ++i) a[i][j] -= f * a[i][K];
+    }
+    if (lane == K) a[0][K] = alpha;
+}
+template <int RPL, int... Ks>
+__device__ __forceinline__ void hh_all(double (&a)[RPL][11], const int lane, std::integer_sequence<int, Ks...>) {
+    (hh_col<Ks, RPL>(a, lane), ...);
+}
+
+template <int RPL>
+__global__ void __launch_bounds__(256)
+resample_eval_reg_kernel(const float* __restrict__ ctrl, const float* __restrict__ cum, int nsub, int S, const float* __restrict__ pp_all,
+                         const int32_t* __restrict__ prof_off, const int4* __restrict__ seginfo, float* __restrict__ pts,
+                         float* __restrict__ tpar, int32_t* __restrict__ seg, float* __restrict__ curv) {
+    constexpr int DEG = 10, NC = DEG + 1;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int4 info = seginfo[s];
+    const int m = nsub + 1;
+    const float* tab = cum + (size_t)s * m;
+    float mn = INFINITY, mx = -INFINITY;
+    float tv[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int r = lane + 64 * i;
+        tv[i] = r < m ? tab[r] : 0.f;
+        if (r < m) { mn = fminf(mn, tv[i]); mx = fmaxf(mx, tv[i]); }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    const double xmin = mn, xmax = mx;
+    const float prec = 1.0f / (float)nsub;
+    double a[RPL][NC];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int r = lane + 64 * i;
+        const double xn = (2 * (double)tv[i] - (xmax + xmin)) / (xmax - xmin);
+        a[i][0] = 1;
+        a[i][1] = xn;
+#pragma unroll
+        for (int j = 2; j < DEG; ++j) a[i][j] = 2 * xn * a[i][j - 1] - a[i][j - 2];
+        const float v = (float)r * prec;
+        a[i][DEG] = v < 1.0f ? v : 1.0f;
+        if (r >= m) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) a[i][j] = 0;
+        }
+    }
+    hh_all<RPL>(a, lane, std::make_integer_sequence<int, DEG>{});
+    // back substitution on rows 0 .. 9 (lanes 0 .. 9, slot 0)
+    double coef[DEG];
+#pragma unroll
+    for (int k = DEG - 1; k >= 0; --k) {
+        double v = a[0][DEG];
+#pragma unroll
+        for (int j = k + 1; j < DEG; ++j) v -= a[0][j] * coef[j];
+        coef[k] = readlane_f64(v / a[0][k], k);
+    }
+    const int start = info.x, end = info.y, b = info.z, il = info.w;
+    const int p0 = prof_off[b], n = prof_off[b + 1] - p0;
+    const float* pp = pp_all + p0;
+    const float* c = ctrl + (size_t)s * 8;
+    const float pstart = end >= start ? pp[start] : 0.f;
+    for (int k = start + lane; k <= end; k += 64) {
+        const int o = k + il;
+        if (o >= n) break;
+        const float xb = pp[k] - pstart;
+        const double xn = (2 * (double)xb - (xmax + xmin)) / (xmax - xmin);
+        double t0 = 1, t1 = xn, y = coef[0] + coef[1] * t1;
+#pragma unroll
+        for (int j = 2; j < DEG; ++j) { const double t2 = 2 * xn * t1 - t0; y += coef[j] * t2; t0 = t1; t1 = t2; }
         float t = (float)y;
         if (t < 0.f) t = 0.f;
         if (t > 1.f) t = 1.f;
@@ -565,10 +753,20 @@ extern "C" int sc_bezier_resample_batch(sc_ctx* ctx, const float* ctrl, const fl
     int4* seginfo = (int4*)ctx->bez_seginfo.p;
     const int m = nsub + 1, nc = (m < 10 ? m : 10) + 1;
     int tk = sc_time_begin(ctx, SC_K_RESAMPLE);
-    hipLaunchKernelGGL(resample_prepare_kernel, dim3(B), dim3(64), 0, ctx->stream, cum, seg_off, nsub, arclength, profile_pos, prof_off,
+    hipLaunchKernelGGL(resample_prepare_kernel, dim3(B), dim3(64), (size_t)RESAMPLE_STAGE_MAX * sizeof(float), ctx->stream, cum, seg_off, nsub, arclength, profile_pos, prof_off,
                        nudge, seginfo, status);
-    hipLaunchKernelGGL(resample_eval_kernel, dim3(S), dim3(256), (size_t)m * nc * sizeof(double), ctx->stream, ctrl, cum, nsub,
-                       (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature);
+    // tables of 10 .. 256 rows: the fit in registers, one wavefront per segment; others: the LDS form, one workgroup per segment
+#define SC_RESAMPLE_REG(RPL)                                                                                                         \
+    hipLaunchKernelGGL(resample_eval_reg_kernel<RPL>, dim3((S + 3) / 4), dim3(256), 0, ctx->stream, ctrl, cum, nsub, S,               \
+                       (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature)
+    if (m >= 10 && m <= 64 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(1);
+    else if (m >= 10 && m <= 128 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(2);
+    else if (m >= 10 && m <= 192 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(3);
+    else if (m >= 10 && m <= 256 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(4);
+    else
+        hipLaunchKernelGGL(resample_eval_kernel, dim3(S), dim3(256), (size_t)m * nc * sizeof(double), ctx->stream, ctrl, cum, nsub,
+                           (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature);
+#undef SC_RESAMPLE_REG
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -821,7 +821,7 @@ static void launch_updown(sc_ctx* ctx, const uint32_t* colbits, int W, int nb, i
 template <int TILES, bool FULL>
 __global__ void __launch_bounds__(1024, 4)
 edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __restrict__ updown, int W, int H, int nb, int nsb, int ngroups,
-                     int32_t* __restrict__ d2, uint16_t* __restrict__ rowbuf, int32_t* __restrict__ fault) {
+                     int32_t* __restrict__ d2, int32_t* __restrict__ fault) {
     static_assert(TILES >= 2 && TILES <= 4, "rows of 1025 .. 4096 pixels");
     constexpr int RB = 16;                          // rows per group
     constexpr int NP = 8;                           // producer wavefronts
@@ -968,8 +968,23 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
         // (at most at step 8: the previous row may have been another map's), runs every step for a while and then at steps
         // an eighth apart.  When to test only affects how many surplus steps run, never the result.
         bool saturated = false;
+        // Open space shows before the first step: 23 adjacent lanes of one stretch whose 16 pixels all carry the clamped
+        // distance (368 columns without an obstacle within 176 rows) hold a pixel that no 175 steps can settle -- straight
+        // to the site search below instead of 175 steps first.  (Sufficient, not necessary: other rows find out at the end.)
+        {
+            constexpr uint32_t OPEN2 = (EDT_W_GCAP * EDT_W_GCAP) * 0x00010001u;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                bool open16 = FULL || W - (1024 * t + 16 * lane) >= 16;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) open16 = open16 && P[t][j] == OPEN2;
+                unsigned long long r = __ballot(open16);
+                r &= r >> 1; r &= r >> 2; r &= r >> 4; r &= r >> 8; r &= r >> 7;      // runs of 2, 4, 8, 16, 23 lanes
+                if (r) saturated = true;
+            }
+        }
         int it = 1, next_chk = max(2, min(hint - 1, 8));
-        for (; it <= EDT_W_ITMAX; ++it) {
+        for (; !saturated && it <= EDT_W_ITMAX; ++it) {
             cascade_step(it);
             const bool last = it == EDT_W_ITMAX;
             if (!last && it < next_chk) continue;
@@ -999,29 +1014,91 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
             if (__ballot(m > thr) == 0) break;
             if (last) { saturated = true; break; }
         }
-        hint = it;
+        if (!saturated) hint = it;
         if (saturated) {
-            // ---- the packed cascade cannot settle this row (a very sparse grid): exact distances as u16 in the wavefront's
-            // row of global scratch, then per pixel an outward scan that stops once k^2 reaches the best value.  Correct
-            // for any input, not fast.
-            uint16_t* row = rowbuf + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * (size_t)W;
-            for (int x = lane; x < W; x += 64) row[x] = (uint16_t)edt_gdist_global(cb, W, nb, b, x, r0 + i);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int x = lane; x < W; x += 64) {
-                const int g0 = __hip_atomic_load(row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int best = g0 * g0;
-                for (int k = 1; k < W && k * k < best; ++k) {
-                    const int xl = x - k, xr = x + k;
-                    const int gl = xl >= 0 ? (int)__hip_atomic_load(row + xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : EDT_G_INF;
-                    const int gr = xr < W ? (int)__hip_atomic_load(row + xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : EDT_G_INF;
-                    const int gm = min(gl, gr);
-                    best = min(best, gm * gm + k * k);
+            // ---- the packed cascade cannot settle this row (distances beyond 175 columns: open space) ----
+            // The row's SITES -- columns with an obstacle anywhere, with their exact vertical distance from the column word
+            // and the up / down word: O(1) per column -- are compacted into the row's own LDS bytes (dead by now), and the
+            // nearest site of a pixel is found through the monotonicity of the argmin (the leftmost nearest site never
+            // moves left as the pixel moves right): one lane per 64-pixel block finds the block's first pixel's site among
+            // all K, then every block's pixels look only between their block's site and the next block's.  K + W / 64
+            // broadcast reads per lane instead of a scan over the whole row per pixel.  Rows with more sites than the row's
+            // bytes hold (WP / 4: a dense region and open space in one row) take several passes, each over the next WP / 4
+            // sites, and keep the minimum.
+            {
+                const uint32_t* ubb = updown + ((size_t)g * nb + b) * W;
+                const uint32_t* cbb = cb + (size_t)b * W;
+                const uint32_t ri = (uint32_t)(r0 + i);
+                constexpr int KMAX = WP / 4;                           // sites per pass: the row's own LDS bytes
+                constexpr uint32_t NOSITE = (uint32_t)EDT_G_INF << 16; // padding: farther than any real site, no overflow
+                const uint4* tr4 = reinterpret_cast<const uint4*>(tr);
+                const int nblk = (W + 63) >> 6;                        // <= 64: one lane per block
+                auto cand = [](const uint32_t sv, const int x) {
+                    const int dx = x - (int)(sv & 0xFFFFu), gq = (int)(sv >> 16);
+                    return gq * gq + dx * dx;
+                };
+                int K = KMAX;                                          // known after the first pass
+                for (int k0 = 0; k0 < K; k0 += KMAX) {                 // KMAX sites at a time (a pass per LDS-full of them)
+                    int seen = 0;
+                    for (int x0 = 0; x0 < W; x0 += 256) {              // four chunks of columns per round trip
+                        uint32_t wv[4], uv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int x = x0 + 64 * u + lane;
+                            wv[u] = x < W ? cbb[x] : 0u;
+                            uv[u] = x < W ? ubb[x] : 0x7FFF7FFFu;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int x = x0 + 64 * u + lane;
+                            const uint32_t wl = wv[u] >> ri, wh = wv[u] << (31u - ri);
+                            uint32_t gg = min(ri + (uv[u] & 0xFFFFu), (31u - ri) + (uv[u] >> 16));
+                            gg = min(gg, (uint32_t)(__ffs((int)wl) - 1));          // 0xFFFFFFFF when no bit at / below the row
+                            gg = min(gg, wh ? (uint32_t)__clz((int)wh) : 0xFFFFFFFFu);
+                            const bool has = x < W && gg < (uint32_t)EDT_G_INF;
+                            const unsigned long long hm = __ballot(has);
+                            const int si = seen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)) - k0;
+                            if (has && si >= 0 && si < KMAX) tr[si] = (uint32_t)x | gg << 16;
+                            seen += __popcll(hm);
+                        }
+                    }
+                    K = seen;
+                    const int Kp = min(K - k0, KMAX);                  // sites of this pass (0: a row without any)
+                    if (lane < 4 && Kp + lane < KMAX) tr[Kp + lane] = NOSITE;       // whole quads of sites are read below
+                    wave_lds_sync();
+                    const int nq = (Kp + 3) >> 2;
+                    int arg = 0;
+                    {
+                        const int xb = 64 * lane;
+                        int best = INT32_MAX;
+                        for (int q = 0; q < nq; ++q) {
+                            const uint4 sv = tr4[q];
+                            const int v0 = cand(sv.x, xb), v1 = cand(sv.y, xb), v2 = cand(sv.z, xb), v3 = cand(sv.w, xb);
+                            if (v0 < best) { best = v0; arg = 4 * q; }          // strictly smaller, left to right: the leftmost
+                            if (v1 < best) { best = v1; arg = 4 * q + 1; }      // of equally near sites
+                            if (v2 < best) { best = v2; arg = 4 * q + 2; }
+                            if (v3 < best) { best = v3; arg = 4 * q + 3; }
+                        }
+                    }
+                    if (k0 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the earlier pass's stores, read back below
+                    for (int bl = 0; bl < nblk; ++bl) {
+                        const int qlo = __builtin_amdgcn_readlane(arg, bl) >> 2;
+                        const int qhi = bl + 1 < nblk ? __builtin_amdgcn_readlane(arg, bl + 1) >> 2 : nq - 1;
+                        const int x = 64 * bl + lane;
+                        int best = INT32_MAX;
+                        for (int q = qlo; q <= qhi && q < nq; ++q) {   // (no site at all: nothing to read)
+                            const uint4 sv = tr4[q];
+                            best = min(min(best, cand(sv.x, x)), min(cand(sv.y, x), min(cand(sv.z, x), cand(sv.w, x))));
+                        }
+                        if (x < W) {
+                            if (k0 > 0) best = min(best, (int)__hip_atomic_load(out + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            out[x] = best >= EDT_F_INF ? INT32_MAX : best;
+                        }
+                    }
+                    wave_lds_sync();
                 }
-                out[x] = best >= EDT_F_INF ? INT32_MAX : best;
+                return;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scratch row is rewritten by this wave's next failed row
-            return;
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -1129,17 +1206,13 @@ static int launch_band_wide(sc_ctx* ctx, const uint32_t* colbits, int W, int H, 
     const int nwg = min(ngroups, ctx->cu_count);
     int tk = ctx->edt_open_token;   // opened in front of the updown launch (-1: timing off)
     ctx->edt_open_token = -1;
-    {   // one row of u16 per wavefront for the rows the packed cascade gives up on
-        int r_ = sc_scratch_reserve(ctx, &ctx->edt_rowbuf, (size_t)nwg * 16 * W * sizeof(uint16_t));
+    if (!ctx->edt_fault.p) {
+        int r_ = sc_scratch_reserve(ctx, &ctx->edt_fault, sizeof(int32_t));
         if (r_ != SC_OK) return r_;
-        if (!ctx->edt_fault.p) {
-            r_ = sc_scratch_reserve(ctx, &ctx->edt_fault, sizeof(int32_t));
-            if (r_ != SC_OK) return r_;
-            SC_HIP(ctx, hipMemsetAsync(ctx->edt_fault.p, 0, sizeof(int32_t), ctx->stream));
-        }
+        SC_HIP(ctx, hipMemsetAsync(ctx->edt_fault.p, 0, sizeof(int32_t), ctx->stream));
     }
     hipLaunchKernelGGL((edt_band_wide_kernel<TILES, FULL>), dim3((unsigned)nwg), dim3(1024), lds, ctx->stream, colbits,
-                       (const uint32_t*)ctx->updown.p, W, H, nb, nsb, ngroups, d2, (uint16_t*)ctx->edt_rowbuf.p, (int32_t*)ctx->edt_fault.p);
+                       (const uint32_t*)ctx->updown.p, W, H, nb, nsb, ngroups, d2, (int32_t*)ctx->edt_fault.p);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -31,7 +31,6 @@ struct sc_ctx {
     // scratch (grow-only)
     sc_scratch colbits;     // EDT: uint32 [batch][nb][W]
     sc_scratch updown;      // EDT, rows wider than 1024: uint32 [batch][nb][W], rows to the nearest obstacle in the bands above / below
-    sc_scratch edt_rowbuf;  // EDT, rows wider than 1024: uint16 [workgroups][16][W], exact distances of a row redone in 32 bits
     sc_scratch edt_fault;   // EDT, rows wider than 1024: int32 [1], set by a wavefront whose bounded wait ran out (read by sc_ctx_synchronize)
     sc_scratch edt_flags;   // EDT, rows wider than 1024: int32 [2][batch][bands], != 0 where a windowed pass gave a band up
     sc_scratch moves;       // A*: uint8 [H][W]

@@ -213,3 +213,40 @@ def test_shrink_tangent_batch_matches_oracle(ctx, oracle):
     wall = np.array([[1.5, -1, 1.5, 1]], np.float32)
     sc.lib().sc_bezier_shrink_tangent_batch_host(ctx._h, p(np.array([[4, 0]], np.float32)), p(np.zeros((1, 2), np.float32)), 1, C.c_float(0.5), p(wall), 1, p(one))
     assert np.allclose(one, [[1.5, 0]])
+
+
+@pytest.mark.parametrize("nsub", [5, 8, 9, 40, 63, 64, 127, 150, 255, 256, 300])
+def test_resample_table_sizes(ctx, oracle, nsub):
+    """The per-segment fit runs in registers for tables of 10 .. 256 rows (one wavefront per segment, 1 .. 4 rows per lane)
+    and in LDS otherwise: every size class, and the sizes either side of each boundary, against the oracle."""
+    import torch
+    rng = np.random.default_rng(1000 + nsub)
+    B = 5
+    ctrls, cums, als, pps, seg_off, prof_off = [], [], [], [], [0], [0]
+    for b in range(B):
+        nwp = int(rng.integers(2, 7))
+        path = np.cumsum(rng.uniform(0.5, 3.0, (nwp, 2)) * rng.choice([-1, 1], (nwp, 2)), axis=0).astype(np.float32)
+        c = oracle.bezier_from_path(path)
+        tot, cum = oracle.bezier_arclength(c, nsub)
+        cum = cum.astype(np.float32)
+        AL = np.float32(cum[:, -1].sum(dtype=np.float32))
+        n = int(rng.integers(30 * (nwp - 1), 300))
+        pp = (np.sort(rng.uniform(0, 1, n)) * AL).astype(np.float32)
+        ctrls.append(c); cums.append(cum); als.append(AL); pps.append(pp)
+        seg_off.append(seg_off[-1] + nwp - 1); prof_off.append(prof_off[-1] + n)
+    dev = "cuda"
+    tpp = torch.from_numpy(np.concatenate(pps)).to(dev)
+    out = ctx.bezier_resample(torch.from_numpy(np.concatenate(ctrls)).to(dev), torch.from_numpy(np.concatenate(cums)).to(dev),
+                              torch.tensor(np.array(als), dtype=torch.float32, device=dev), torch.tensor(seg_off, dtype=torch.int32, device=dev),
+                              tpp, torch.tensor(prof_off, dtype=torch.int32, device=dev), nudge=True)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for b in range(B):
+        ref = oracle.bezier_resample(ctrls[b], cums[b], als[b], pps[b], True)
+        sl = slice(prof_off[b], prof_off[b + 1])
+        assert got["status"][b] == ref["status"], b
+        if ref["status"]:
+            continue
+        assert np.array_equal(got["seg"][sl], ref["seg"]), b
+        assert np.abs(got["t"][sl] - ref["t"]).max() < 5e-7, b
+        assert np.abs(got["pts"][sl] - ref["pts"]).max() < 1e-5, b

@@ -212,3 +212,30 @@ def test_two_contexts_two_threads_big_lds_kernels(oracle):
     assert not errs, errs
     for i in range(2):
         assert np.array_equal(res[i], refs[i]), i
+
+
+@pytest.mark.parametrize("W", [1100, 2048, 3000, 4096])
+def test_edt_wide_open_space(ctx, oracle, W):
+    """Rows the packed cascade cannot settle (distances beyond 175 columns) go through the site search: the columns with an
+    obstacle, compacted, and the monotone nearest-site rule.  Cases: a handful of obstacles (few sites), a dense half beside
+    an empty half (more sites than one pass holds: several passes), obstacles only in the last / first columns, one full
+    column, and a tall sparse grid whose vertical distances exceed a band by far."""
+    import torch
+    rng = np.random.default_rng(W + 1)
+    H = 96
+    few = np.zeros((H, W), np.uint8)
+    for _ in range(9):
+        few[rng.integers(0, H), rng.integers(0, W)] = 1
+    half = np.zeros((H, W), np.uint8)
+    half[:, :W // 2] = (rng.random((H, W // 2)) < 0.3)
+    half[:, W // 2 + 40:] = 0
+    ends = np.zeros((H, W), np.uint8); ends[5, W - 1] = 1; ends[H - 2, 0] = 1
+    col = np.zeros((H, W), np.uint8); col[:, W // 3] = 1
+    dense_left = np.zeros((H, W), np.uint8); dense_left[::2, :W - 400] = 1      # every column a site for most of the row, open space at its end
+    occ = np.stack([few, half, ends, col, dense_left])
+    got = ctx.edt(torch.from_numpy(occ).cuda()).cpu().numpy()
+    for b in range(occ.shape[0]):
+        assert np.array_equal(got[b], oracle.edt(occ[b])), b
+    tall = (rng.random((1500, W)) < 3e-5).astype(np.uint8)
+    tall[0, 0] = 1
+    assert np.array_equal(ctx.edt(torch.from_numpy(tall).cuda()).cpu().numpy(), oracle.edt(tall))

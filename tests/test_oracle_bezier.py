@@ -154,3 +154,15 @@ def test_shrink_tangent_on_its_own_closed_forms(oracle):
     assert np.allclose(oracle.bezier_shrink_tangent(T[3:4], Wp[3:4], 1.0, [[0, 2.5, 2, 2.5]]), [[0, 1.5]])          # vertical tangent, horizontal wall
     assert np.allclose(oracle.bezier_shrink_tangent(T[4:5], Wp[4:5], 0.5, [wall(1.5, -1, 1), wall(-1.0, -1, 1)]), [[1.0, 0]])   # first the front wall, then the rear one cuts further
     assert np.allclose(oracle.bezier_shrink_tangent(T[:1], Wp[:1], 0.5, [[1.5, 0.5, 1.5, 2.0]]), [[2.0, 0]])        # the wall does not reach the tangent's line
+
+
+def test_smooth_one_reproduces_the_recorded_run(oracle, golden_dir):
+    """oracle.smooth_one (the CPU composition the batched GPU sequence is checked against) on the reference's own request
+    (examples/zmq_test.py:7-10) against examples/output.json."""
+    import os
+    fx = np.load(os.path.join(golden_dir, "toppra_1dof_output.npz"))
+    r = oracle.smooth_one(fx["waypoints"], vmax=float(fx["vel_lim"][1]), amax=float(fx["acc_lim"][1]), dt=0.02, N=100)
+    assert r["status"] == 0 and r["toppra_status"] == 0 and r["length"] == fx["pos"].shape[0]
+    assert abs(float(r["arclength"]) - float(fx["arclength"])) < 2e-6 * float(fx["arclength"])
+    assert np.abs(r["pts"][:, 0] - fx["pos_x"]).max() < 5e-5 and np.abs(r["pts"][:, 1] - fx["pos_y"]).max() < 5e-5
+    assert np.abs(r["vel"] * r["curvature"] - fx["ang_vel"]).max() < 2e-6

@@ -7,7 +7,14 @@ cd "$(dirname "$0")/../sea-current_amd"
 name=$1; shift
 mkdir -p variants
 make -s all
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c ${ASTAR_SRC:-csrc/astar.hip} -o variants/$name.astar.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so csrc/ctx.o csrc/edt.o variants/$name.astar.o csrc/toppra.o csrc/bezier.o csrc/grid.o csrc/fmt.o csrc/gather.o -ldl
-rm -f variants/$name.astar.o
+unit=${VARIANT_UNIT:-astar}     # which source is rebuilt with the macros (astar, edt, bezier, ...)
+src=csrc/$unit.hip
+[ $unit = astar ] && src=${ASTAR_SRC:-csrc/astar.hip}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $src -o variants/$name.$unit.o
+objs=""
+for o in ctx edt astar toppra bezier grid fmt gather; do
+  if [ $o = $unit ]; then objs="$objs variants/$name.$unit.o"; else objs="$objs csrc/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so $objs -ldl
+rm -f variants/$name.$unit.o
 echo built variants/$name.so

@@ -15,6 +15,7 @@ FAMS = sys.argv[4].split(",") if len(sys.argv) > 4 else ("salt05", "salt20", "bl
 for fam in FAMS:
     grids = torch.from_numpy(np.stack([
         synth.salt_grid(W, H, 0.05, seed=100 + i) if fam == "salt05" else
+        synth.salt_grid(W, H, float(fam[6:]), seed=100 + i) if fam.startswith("sparse") else   # sparse2e-5 ...: rows the packed cascade cannot settle
         synth.salt_grid(W, H, 0.20, seed=100 + i) if fam == "salt20" else
         synth.block_grid(W, H, 0.20, seed=100 + i) for i in range(B)])).cuda()
     d2 = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
