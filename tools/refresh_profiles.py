@@ -10,6 +10,8 @@ for f in ("bench_default", "bench_forced_dist", "bench_steps20"):
     shutil.copy(os.path.join(src, f + ".json"), os.path.join(dst, f"{tag}_{f}.json"))
 shutil.copy(os.path.join(src, "bench_stats", "b_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "toppra_stats", "t_kernel_stats.csv"), os.path.join(dst, f"{tag}_toppra_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "smoothing_stats", "s_kernel_stats.csv")):   # tools/smoothing_one.py under rocprofv3 --kernel-trace --stats
+    shutil.copy(os.path.join(src, "smoothing_stats", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_smoothing_kernel_stats.csv"))
 for d in sorted(os.listdir(src)):
     m = re.match(r"edt_stats_(\d+)_(\d+)_(\w+)$", d)
     if m and os.path.isdir(os.path.join(src, d)):

@@ -54,6 +54,8 @@ timeout -k 5 120 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_W
 echo toppra pmc done
 timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/toppra_stats -o t -- python3 $R/tools/toppra_one.py > $O/toppra_stats.log 2>&1
 echo toppra stats done
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/smoothing_stats -o s -- python3 $R/tools/smoothing_one.py > $O/smoothing_stats.log 2>&1
+echo smoothing stats done
 timeout -k 5 60 $R/tools/microbench/min3_mb.bin > $O/min3_mb.log 2>&1 || true
 timeout -k 5 60 $R/tools/microbench/lds_mb.bin > $O/lds_mb.log 2>&1 || true
 echo all done
