@@ -592,6 +592,43 @@ def main():
             result["smoothing"]["cpu"] = {"paths_per_s": len(refs) / t_c, "cores": 1, "kind": "port", "sample": f"the first {len(refs)} paths of the batch",
                                           "gpu_matches_cpu_on_sample": bool(okp)}
 
+    # ---- the reference's own planner, FMT* over Halton samples, batched: reported, not part of `value` ----
+    if rank == 0 and world == 1 and not args.only_main_map:
+        fl, fo = synth.polygon_world(14, 5.0)
+        fs = synth.free_samples(1000, 5.0, fl, fo)
+        frng = np.random.default_rng(0xF37)
+        Qf = 1024
+        fst, fgo = fs[frng.integers(0, fs.shape[0], Qf)], fs[frng.integers(0, fs.shape[0], Qf)]
+        td = lambda a_: torch.from_numpy(np.ascontiguousarray(a_, np.float32)).to(dev)
+        fsd, fstd, fgod, fld = td(fs), td(fst), td(fgo), td(fl)
+        fo_ = ctx.fmt_star(fsd, fstd, fgod, 0.9, fld, Lmax=128)
+        ctx.synchronize()
+        ctx.reset_timing(); ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fo_ = ctx.fmt_star(fsd, fstd, fgod, 0.9, fld, Lmax=128)
+        ctx.synchronize()
+        t_f = (time.perf_counter() - t0) / 3
+        ms_f = ctx.get_timing(sc.K_FMT)[0] / 3
+        ctx.set_timing(False)
+        fstat = fo_["status"].cpu().numpy()
+        result["fmt_star"] = {"workload": f"{Qf} start-goal pairs over 1000 Halton samples of a 10 x 10 world with 14 convex polygons ({fl.shape[0]} edges), "
+                                          "connection radius 0.9: fast_marching_trees (sea_current.hpp:1339-1407), one wavefront per query",
+                              "queries": Qf, "ms_per_batch": t_f * 1e3, "ms_kernel": ms_f, "plans_per_s": Qf / t_f, "found": int((fstat == 0).sum()),
+                              "note": "the reference's planner restated (parity vs the reference unpinned: it holds no recorded FMT* output); per query "
+                                      "the tree grows over up to 1002 samples with a segment-vs-every-edge test per candidate connection"}
+        if not args.no_cpu_baseline:
+            from oracle import oracle  # checker / baseline only
+            oracle.build()
+            t0 = time.perf_counter()
+            frefs = [oracle.fmt_star(fs, fst[q_], fgo[q_], 0.9, fl, Lmax=128) for q_ in range(32)]
+            t_c = time.perf_counter() - t0
+            fp_, fl_, fc_ = fo_["path"].cpu().numpy(), fo_["len"].cpu().numpy(), fo_["cost"].cpu().numpy()
+            okf = all(fstat[q_] == r_["status"] and (r_["status"] != 0 or (fl_[q_] == r_["len"] and fc_[q_] == np.float32(r_["cost"])
+                                                                           and np.array_equal(fp_[q_, :r_["len"]], r_["path"]))) for q_, r_ in enumerate(frefs))
+            result["fmt_star"]["cpu"] = {"plans_per_s": len(frefs) / t_c, "cores": 1, "kind": "port", "sample": "the first 32 queries of the batch",
+                                         "gpu_matches_cpu_on_sample": bool(okf)}
+
     # ---- CPU baseline leg (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker / baseline only, never the measured product

@@ -49,7 +49,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
     for (auto& p : ctx->pending) { if (!p.shared_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
-    free_scratch(&ctx->colbits); free_scratch(&ctx->updown); free_scratch(&ctx->edt_fault); free_scratch(&ctx->edt_flags); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
+    free_scratch(&ctx->colbits); free_scratch(&ctx->updown); free_scratch(&ctx->edt_fault); free_scratch(&ctx->fmt_nbr); free_scratch(&ctx->edt_flags); free_scratch(&ctx->moves); free_scratch(&ctx->gslots);
     free_scratch(&ctx->buckets); free_scratch(&ctx->qstats); free_scratch(&ctx->closed); free_scratch(&ctx->actr); free_scratch(&ctx->bez_tang); free_scratch(&ctx->bez_gl); free_scratch(&ctx->bez_seginfo); free_scratch(&ctx->cheb_a); free_scratch(&ctx->gather_msg);
     for (auto& s : ctx->staging) free_scratch(&s);
     (void)hipStreamDestroy(ctx->own_stream);
@@ -127,7 +127,7 @@ int sc_scratch_reserve(sc_ctx* ctx, sc_scratch* s, size_t bytes) {
 extern "C" int sc_ctx_scratch_bytes(sc_ctx* ctx, int64_t* bytes) {
     if (!ctx || !bytes) return SC_ERR_INVALID;
     size_t b = ctx->colbits.bytes + ctx->updown.bytes + ctx->edt_fault.bytes + ctx->edt_flags.bytes + ctx->moves.bytes + ctx->gslots.bytes + ctx->closed.bytes + ctx->buckets.bytes +
-               ctx->qstats.bytes + ctx->actr.bytes + ctx->bez_tang.bytes + ctx->bez_gl.bytes + ctx->bez_seginfo.bytes + ctx->cheb_a.bytes + ctx->gather_msg.bytes;
+               ctx->qstats.bytes + ctx->actr.bytes + ctx->bez_tang.bytes + ctx->bez_gl.bytes + ctx->bez_seginfo.bytes + ctx->cheb_a.bytes + ctx->gather_msg.bytes + ctx->fmt_nbr.bytes;
     for (auto& s : ctx->staging) b += s.bytes;
     *bytes = (int64_t)b;
     return SC_OK;

@@ -7,9 +7,9 @@
 // costs) the lowest node index wins.  Built with -ffp-contract=off: every float operation is the reference's.
 //
 // One wavefront per query, the whole node table in LDS (coordinates, cost-to-come, parent, state).  Per iteration:
-// the unvisited neighbours of z are compacted by ballot rank; for each of them the lanes scan the open set in
-// parallel (radius test, collision test against all obstacle edges, cost-to-come + length) and a wave reduction picks
-// the cheapest parent; the next z is a wave arg-min over the open set.  Nodes: 0..n-1 samples, n goal, n+1 start.
+// the unvisited neighbours of z are compacted by ballot rank; for each of them the open nodes in range are compacted
+// too, their segments are tested against the obstacle edges with a lane per (node, edge) pair, and a wave reduction
+// picks the cheapest parent (cost-to-come + length); the next z is a wave arg-min over the open set.  Nodes: 0..n-1 samples, n goal, n+1 start.
 #include "sc_internal.h"
 
 #include <cfloat>
@@ -21,7 +21,9 @@ struct fmt_args {
     const float* lines; int E;
     int Lmax;
     float* path; int32_t* len; float* cost; int32_t* status;
+    const uint16_t* nbr; const int32_t* nbr_cnt; const int32_t* nbr_ovf;   // per sample: the samples in range, ascending (fmt_neighbors_kernel)
 };
+#define FMT_NBR_CAP 256
 
 __device__ __forceinline__ float fmt_dist(float ax, float ay, float bx, float by) {
     const float dx = bx - ax, dy = by - ay;
@@ -53,6 +55,34 @@ __device__ __forceinline__ void fmt_argmin(float& v, int& i) {
     }
 }
 
+// The samples are shared by the queries of a batch and `near` depends on positions only: the samples in range of every
+// sample, once per batch (one wavefront per sample, ascending by ballot rank, the predicate of the scans below).  A search
+// then reads a node's list instead of scanning all n samples for every z and every x (6 scans of 16 steps per iteration
+// at n = 1000).  A sample with more than FMT_NBR_CAP in range sets *ovf and the batch falls back to the scans.
+__global__ void __launch_bounds__(64) fmt_neighbors_kernel(const float* __restrict__ samples, int n, float rn, uint16_t* __restrict__ nbr,
+                                                            int32_t* __restrict__ cnt_out, int32_t* __restrict__ ovf) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const float zx = samples[2 * i], zy = samples[2 * i + 1];
+    const double r2 = (double)rn * (double)rn;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        bool ok = false;
+        if (j < n) {
+            const float jx = samples[2 * j], jy = samples[2 * j + 1];
+            ok = (double)fmt_dist(jx, jy, zx, zy) <= r2 && !(jx == zx && jy == zy);
+        }
+        const unsigned long long m = __ballot(ok);
+        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (ok && pos < FMT_NBR_CAP) nbr[(size_t)i * FMT_NBR_CAP + pos] = (uint16_t)j;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) {
+        cnt_out[i] = cnt;
+        if (cnt > FMT_NBR_CAP) *ovf = 1;
+    }
+}
+
 __global__ void __launch_bounds__(64) fmt_kernel(fmt_args a) {
     extern __shared__ float4 smem4[];
     const int lane = threadIdx.x, q = blockIdx.x;
@@ -63,7 +93,9 @@ __global__ void __launch_bounds__(64) fmt_kernel(fmt_args a) {
     float* cst = py + N;
     uint16_t* par = reinterpret_cast<uint16_t*>(cst + N);    // [N]
     uint16_t* xl = par + N;                                  // [N] compacted neighbours of z
-    uint8_t* st = reinterpret_cast<uint8_t*>(xl + N);        // [N] 0 unvisited, 1 open, 2 closed, 5 opened this iteration
+    uint16_t* yl = xl + N;                                   // [N] compacted open nodes near the current x
+    uint8_t* st = reinterpret_cast<uint8_t*>(yl + N);        // [N] 0 unvisited, 1 open, 2 closed, 5 opened this iteration
+    uint8_t* hit = st + N;                                   // [N] per entry of yl: its segment to x crosses an obstacle edge
     const float sx = a.starts[2 * q], sy = a.starts[2 * q + 1], gx = a.goals[2 * q], gy = a.goals[2 * q + 1];
     for (int e = lane; e < E; e += 64) lines[e] = reinterpret_cast<const float4*>(a.lines)[e];
     for (int i = lane; i < N; i += 64) {
@@ -75,36 +107,79 @@ __global__ void __launch_bounds__(64) fmt_kernel(fmt_args a) {
     }
     __syncthreads();
     const double r2 = (double)a.rn * (double)a.rn;
+    const bool lists = a.nbr != nullptr && *a.nbr_ovf == 0;
+    // the nodes in range of node c with state `want`, compacted in index order into `dst`: from c's list (samples) plus the
+    // two nodes of the query itself, or by a scan over all nodes (c is the start or the goal; no lists)
+    auto in_range = [&](const int c, const float cx, const float cy, const uint8_t want, uint16_t* dst) {
+        int cnt = 0;
+        auto take = [&](const bool ok, const int i) {
+            const unsigned long long m = __ballot(ok);
+            if (ok) dst[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+            cnt += __popcll(m);
+        };
+        if (lists && c < n) {
+            const int nc = a.nbr_cnt[c];
+            const uint16_t* l = a.nbr + (size_t)c * FMT_NBR_CAP;
+            for (int base = 0; base < nc; base += 64) {
+                const int k = base + lane;
+                const int i = k < nc ? (int)l[k] : 0;
+                take(k < nc && st[i] == want, i);
+            }
+            const int i = n + lane;                          // goal, start
+            bool ok = false;
+            if (lane < 2 && st[i] == want) ok = (double)fmt_dist(px[i], py[i], cx, cy) <= r2 && !(px[i] == cx && py[i] == cy);
+            take(ok, i);
+        } else {
+            for (int base = 0; base < N; base += 64) {
+                const int i = base + lane;
+                bool ok = false;
+                if (i < N && st[i] == want) ok = (double)fmt_dist(px[i], py[i], cx, cy) <= r2 && !(px[i] == cx && py[i] == cy);
+                take(ok, i);
+            }
+        }
+        return cnt;
+    };
     int z = INIT;
     bool found = true;
     while (!(px[z] == gx && py[z] == gy)) {
         const float zx = px[z], zy = py[z];
-        int cnt = 0;
-        for (int base = 0; base < N; base += 64) {
-            const int i = base + lane;
-            bool ok = false;
-            if (i < N && st[i] == 0) ok = (double)fmt_dist(px[i], py[i], zx, zy) <= r2 && !(px[i] == zx && py[i] == zy);
-            const unsigned long long m = __ballot(ok);
-            if (ok) xl[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
-            cnt += __popcll(m);
-        }
+        const int cnt = in_range(z, zx, zy, 0, xl);
         __syncthreads();
         for (int k = 0; k < cnt; ++k) {
             const int x = xl[k];
             const float xx = px[x], xy = py[x];
-            float best = 0.f;
-            int bi = -1;
-            for (int y = lane; y < N; y += 64) {
-                if (st[y] != 1) continue;
-                const float yx = px[y], yy = py[y];
-                if (!((double)fmt_dist(yx, yy, xx, xy) <= r2) || (yx == xx && yy == xy)) continue;
-                const float cy = cst[y] + fmt_edge_cost(xx, xy, yx, yy, lines, E);
-                if (bi < 0 || cy < best) { best = cy; bi = y; }
+            // the open nodes near x, compacted in index order ...
+            const int m = in_range(x, xx, xy, 1, yl);
+            for (int j = lane; j < m; j += 64) hit[j] = 0;
+            wave_lds_sync();
+            // ... their segments to x against every obstacle edge, a lane per (node, edge) pair (the same float operations per
+            // pair as one lane walking a node's edges; that way the walk ran for a whole wavefront whenever one lane had a
+            // node in range: 62 edges x 16 scan steps per x, mostly idle) ...
+            for (int p = lane; p < m * E; p += 64) {
+                const int j = p / E, e = p - j * E;
+                const int y = yl[j];
+                if (fmt_hit(xx, xy, px[y], py[y], lines[e])) hit[j] = 1;
             }
-            fmt_argmin(best, bi);
-            if (bi >= 0) {
-                const float ec = fmt_edge_cost(xx, xy, px[bi], py[bi], lines, E);
-                if (ec != FLT_MAX && lane == 0) { par[x] = (uint16_t)bi; cst[x] = cst[bi] + ec; st[x] = 5; }
+            wave_lds_sync();
+            // ... and the cheapest parent: cost-to-come + length, FLT_MAX through an obstacle; equal costs: the lowest index
+            float best = 0.f, bec = 0.f;
+            int bj = -1;
+            for (int j = lane; j < m; j += 64) {
+                const int y = yl[j];
+                const float ec = hit[j] ? FLT_MAX : fmt_dist(xx, xy, px[y], py[y]);
+                const float cy = cst[y] + ec;
+                if (bj < 0 || cy < best) { best = cy; bj = j; bec = ec; }
+            }
+            {
+                int wj = bj;
+                fmt_argmin(best, wj);
+                // the winner's edge cost: from the lane that held it
+                const unsigned long long own = __ballot(bj == wj && wj >= 0);
+                if (wj >= 0) {
+                    const float ec = __shfl(bec, __ffsll((long long)own) - 1);
+                    const int bi = yl[wj];
+                    if (ec != FLT_MAX && lane == 0) { par[x] = (uint16_t)bi; cst[x] = cst[bi] + ec; st[x] = 5; }
+                }
             }
             wave_lds_sync();
         }
@@ -149,9 +224,20 @@ extern "C" int sc_fmt_star_batch(sc_ctx* ctx, const float* samples, int n, const
     if (Q == 0) return SC_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const int N = n + 2;
-    const size_t lds = (size_t)E * 16 + (size_t)N * (3 * 4 + 2 * 2 + 1) + 16;
-    fmt_args a{samples, n, starts, goals, Q, rn, lines, E, Lmax, path, len, cost, status};
+    const size_t lds = (size_t)E * 16 + (size_t)N * (3 * 4 + 3 * 2 + 2) + 16;
+    // neighbour lists of the samples: fmt_nbr = uint16 [n][FMT_NBR_CAP] | int32 count [n] | int32 overflow
+    const size_t nb_bytes = (size_t)n * FMT_NBR_CAP * sizeof(uint16_t);
+    int r = sc_scratch_reserve(ctx, &ctx->fmt_nbr, nb_bytes + ((size_t)n + 1) * sizeof(int32_t) + 16);
+    if (r != SC_OK) return r;
+    uint16_t* nbr = (uint16_t*)ctx->fmt_nbr.p;
+    int32_t* ncnt = (int32_t*)((char*)ctx->fmt_nbr.p + ((nb_bytes + 15) & ~(size_t)15));
+    int32_t* novf = ncnt + n;
+    fmt_args a{samples, n, starts, goals, Q, rn, lines, E, Lmax, path, len, cost, status, n > 0 ? nbr : nullptr, ncnt, novf};
     int tk = sc_time_begin(ctx, SC_K_FMT);
+    if (n > 0) {
+        SC_HIP(ctx, hipMemsetAsync(novf, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(fmt_neighbors_kernel, dim3(n), dim3(64), 0, ctx->stream, samples, n, rn, nbr, ncnt, novf);
+    }
     hipLaunchKernelGGL(fmt_kernel, dim3(Q), dim3(64), lds, ctx->stream, a);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());

@@ -43,6 +43,7 @@ struct sc_ctx {
     sc_scratch bez_gl;      // Bezier: 32 Gauss-Legendre nodes + 32 weights
     sc_scratch bez_seginfo; // resample: int4 [S] (first sample, last sample, spline, segment in spline)
     sc_scratch cheb_a;      // chebfit: double [rows][degree + 1], the [T | y] matrices of a batch
+    sc_scratch fmt_nbr;     // FMT*: uint16 [n][256] samples in range of every sample | int32 count [n] | int32 overflow
     sc_scratch gather_msg;  // gather: this rank's message, every rank's messages, local offsets
     sc_scratch staging[8];  // _host wrappers
     int astar_cap = 1 << 16;          // ring entries per bucket (power of two)

@@ -127,3 +127,54 @@ def toppra_plans(P, dof=6, seed=SEED_TOPPRA, first=0):
     vl = np.resize(np.array([2, 2, 2, 3, 3, 3.0]), dof)
     al = np.resize(np.array([5, 5, 5, 8, 8, 8.0]), dof)
     return dict(p0=p0, p1=p1, v0=v0, v1=v1, vlim=np.tile(vl, (P, 1)), alim=np.tile(al, (P, 1)))
+
+
+def polygon_world(n_poly=14, half=5.0, seed=SEED_GRID):
+    """Convex polygons (3 .. 6 corners, radius 0.3 .. 1.0) scattered over [-0.8 half, 0.8 half]^2 -> (lines float32 [E,4]
+    (x0, y0, x1, y1 per edge), obs_off int32 [n_poly+1]): the obstacle form of the reference's planning_space
+    (sea_current.hpp:193-284), for the FMT* leg of the bench and its tests."""
+    rng = np.random.default_rng(seed)
+    lines, off = [], [0]
+    for _ in range(n_poly):
+        c = rng.uniform(-0.8 * half, 0.8 * half, 2)
+        r = rng.uniform(0.3, 1.0)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, int(rng.integers(3, 7))))
+        q = [(c[0] + r * np.cos(a), c[1] + r * np.sin(a)) for a in ang]
+        for i in range(len(q)):
+            lines.append(tuple(q[i]) + tuple(q[(i + 1) % len(q)]))
+        off.append(len(lines))
+    return np.array(lines, np.float32).reshape(-1, 4), np.array(off, np.int32)
+
+
+def _halton(base, n, skip=20):
+    out = np.empty(n, np.float64)
+    for k in range(n):
+        f, r, i = 1.0, 0.0, k + 1 + skip
+        while i > 0:
+            f /= base
+            r += f * (i % base)
+            i //= base
+        out[k] = r
+    return out
+
+
+def free_samples(n, half, lines, obs_off, seed=0):
+    """n Halton points (bases 2, 3) of [-half, half]^2 outside every polygon (even-odd ray casting) -> float32 [n,2].  A
+    generator of inputs for the bench: the reference's own sample_free (:1294-1313) is restated in oracle/ and in the header."""
+    pts = []
+    k = 0
+    while len(pts) < n:
+        m = 2 * (n - len(pts)) + 16
+        hx = _halton(2, m + k)[k:]
+        hy = _halton(3, m + k)[k:]
+        k += m
+        P = np.stack([(2 * hx - 1) * half, (2 * hy - 1) * half], axis=1)
+        inside = np.zeros(P.shape[0], bool)
+        for o in range(obs_off.shape[0] - 1):
+            cnt = np.zeros(P.shape[0], np.int32)
+            for (x0, y0, x1, y1) in lines[obs_off[o]:obs_off[o + 1]].astype(np.float64):
+                cross = ((y0 > P[:, 1]) != (y1 > P[:, 1])) & (P[:, 0] < (x1 - x0) * (P[:, 1] - y0) / (y1 - y0 + 1e-300) + x0)
+                cnt += cross
+            inside |= (cnt & 1) == 1
+        pts.extend(P[~inside].tolist())
+    return np.array(pts[:n], np.float32)
