@@ -919,6 +919,8 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
     };
 
     int hint = 4;   // cascade steps the wave's previous row needed (rows claimed in a row are often neighbours)
+    int open_rows = 0;   // rows in a row that this wave could not settle by the packed cascade (open space)
+    int open_sites = 0;  // ... and the number of sites of the last of them
     // ---- row i of group n: cascade, transposition, stores ----
     auto consume_row = [&](int n, int i) {
         const int s = (int)vid + n * (int)nwg;
@@ -983,6 +985,10 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
                 if (r) saturated = true;
             }
         }
+        // After a row of open space with few sites (the search then costs less than the 175 steps that settled nothing) the
+        // wave's next rows go to the site search at once, except every eighth, which tries the cascade again.  (A row that
+        // would have settled costs at most about twice as much that way; maps without open space never get here.)
+        if ((open_rows & 7) != 0 && open_sites <= 512) saturated = true;
         int it = 1, next_chk = max(2, min(hint - 1, 8));
         for (; !saturated && it <= EDT_W_ITMAX; ++it) {
             cascade_step(it);
@@ -1014,8 +1020,9 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
             if (__ballot(m > thr) == 0) break;
             if (last) { saturated = true; break; }
         }
-        if (!saturated) hint = it;
+        if (!saturated) { hint = it; open_rows = 0; }
         if (saturated) {
+            ++open_rows;
             // ---- the packed cascade cannot settle this row (distances beyond 175 columns: open space) ----
             // The row's SITES -- columns with an obstacle anywhere, with their exact vertical distance from the column word
             // and the up / down word: O(1) per column -- are compacted into the row's own LDS bytes (dead by now), and the
@@ -1063,6 +1070,7 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
                         }
                     }
                     K = seen;
+                    open_sites = K;
                     const int Kp = min(K - k0, KMAX);                  // sites of this pass (0: a row without any)
                     if (lane < 4 && Kp + lane < KMAX) tr[Kp + lane] = NOSITE;       // whole quads of sites are read below
                     wave_lds_sync();
