@@ -759,10 +759,12 @@ extern "C" int sc_bezier_resample_batch(sc_ctx* ctx, const float* ctrl, const fl
 #define SC_RESAMPLE_REG(RPL)                                                                                                         \
     hipLaunchKernelGGL(resample_eval_reg_kernel<RPL>, dim3((S + 3) / 4), dim3(256), 0, ctx->stream, ctrl, cum, nsub, S,               \
                        (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature)
-    if (m >= 10 && m <= 64 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(1);
-    else if (m >= 10 && m <= 128 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(2);
-    else if (m >= 10 && m <= 192 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(3);
-    else if (m >= 10 && m <= 256 && !getenv("SC_RESAMPLE_LDS")) SC_RESAMPLE_REG(4);
+    static const bool lds_form = getenv("SC_RESAMPLE_LDS") != nullptr;   // A/B switch: the LDS form for every table size
+    const bool reg = !lds_form && m >= 10;
+    if (reg && m <= 64) SC_RESAMPLE_REG(1);
+    else if (reg && m <= 128) SC_RESAMPLE_REG(2);
+    else if (reg && m <= 192) SC_RESAMPLE_REG(3);
+    else if (reg && m <= 256) SC_RESAMPLE_REG(4);
     else
         hipLaunchKernelGGL(resample_eval_kernel, dim3(S), dim3(256), (size_t)m * nc * sizeof(double), ctx->stream, ctrl, cum, nsub,
                            (const float*)profile_pos, prof_off, (const int4*)seginfo, pts, tpar, seg, curvature);
