@@ -98,6 +98,8 @@ extern "C" int sc_ctx_synchronize(sc_ctx* ctx) {
             if (ctx->astar_cap < (1 << 22)) ctx->astar_cap *= 4;
         }
     }
+    r = sc_edt_open_mode_update(ctx);
+    if (r != SC_OK) return r;
     // the wide-row EDT kernel's wavefronts wait for one another with bounded spins: one that ran out left rows unwritten
     if (ctx->edt_fault.p) {
         int32_t fault = 0;

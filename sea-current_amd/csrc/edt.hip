@@ -1232,6 +1232,89 @@ static int launch_band_wide_t(sc_ctx* ctx, const uint32_t* colbits, int W, int H
                              : launch_band_wide<TILES, false>(ctx, colbits, W, H, nb, batch, d2);
 }
 
+// Open space at widths up to 1024 (a hint between launches, per device): [0] a row of edt_band_k16_kernel<.., false> took the
+// 32-bit fallback; [1] a row of its OPEN build took the site search.  sc_ctx_synchronize reads and clears them: a context
+// that has seen [0] runs the OPEN build (with edt_updown_kernel in front) until a launch of it leaves [1] clear.
+__device__ int32_t g_edt_open[2];
+
+// One row of open space by the site search, for edt_band_k16_kernel's OPEN build: the row's sites -- obstacle columns with
+// their exact vertical distance, from the band's column word and its up / down word -- compacted in column order into 512
+// words of LDS (SA: the wave's transposition buffer, SB: the first KiB of its first row's bytes), then the monotone
+// nearest-site rule (see edt_band_wide_kernel) with a lane per 16 pixels: lane l finds the nearest site of its first pixel
+// among all K, and its 16 pixels look only between that site and lane l + 1's.  Returns K; writes nothing when K > 508.
+template <bool FULL>
+__device__ __forceinline__ int edt_k16_site_row(const uint32_t* __restrict__ cbrow, const uint32_t* __restrict__ ubrow, const int W, const int i,
+                                                const int lane, uint32_t* const SA, uint32_t* const SB, int32_t* __restrict__ out) {
+    constexpr uint32_t NOSITE = (uint32_t)EDT_G_INF << 16;
+    const int nvalid = W - 16 * lane;
+    const uint32_t* ubb = ubrow + 16 * lane;
+    const uint32_t* cbb = cbrow + 16 * lane;
+    const uint32_t ri = (uint32_t)i;
+    auto site = [&](const int s) -> uint32_t& { return s < 256 ? SA[s] : SB[s - 256]; };
+    auto gdist16 = [&](const int j) -> uint32_t {              // exact vertical distance of pixel j of this lane (INF: none)
+        if (!FULL && j >= nvalid) return EDT_G_INF;
+        const uint32_t w = cbb[j], ud = ubb[j];
+        const uint32_t wl = w >> ri, wh = w << (31u - ri);
+        uint32_t gg = min(ri + (ud & 0xFFFFu), (31u - ri) + (ud >> 16));
+        gg = min(gg, (uint32_t)(__ffs((int)wl) - 1));
+        gg = min(gg, wh ? (uint32_t)__clz((int)wh) : 0xFFFFFFFFu);
+        return min(gg, (uint32_t)EDT_G_INF);
+    };
+    int cnt = 0;
+    for (int j = 0; j < 16; ++j) cnt += gdist16(j) < (uint32_t)EDT_G_INF;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int K = __builtin_amdgcn_readlane(incl, 63);
+    if (K > 508) return K;
+    int pos = incl - cnt;
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t gg = gdist16(j);
+        if (gg < (uint32_t)EDT_G_INF) site(pos++) = (uint32_t)(16 * lane + j) | gg << 16;
+    }
+    if (lane < 4) site(K + lane) = NOSITE;                     // whole quads of sites are read below
+    wave_lds_sync();
+    auto cand = [](const uint32_t sv, const int x) {
+        const int dx = x - (int)(sv & 0xFFFFu), gq = (int)(sv >> 16);
+        return gq * gq + dx * dx;
+    };
+    const int nq = (K + 3) >> 2;
+    int arg = 0;
+    {
+        const int xb = 16 * lane;
+        int best = INT32_MAX;
+        for (int q = 0; q < nq; ++q) {
+            const uint4 sv = *reinterpret_cast<const uint4*>(q < 64 ? SA + 4 * q : SB + 4 * (q - 64));
+            const int v0 = cand(sv.x, xb), v1 = cand(sv.y, xb), v2 = cand(sv.z, xb), v3 = cand(sv.w, xb);
+            if (v0 < best) { best = v0; arg = 4 * q; }          // strictly smaller, left to right: the leftmost of
+            if (v1 < best) { best = v1; arg = 4 * q + 1; }      // equally near sites
+            if (v2 < best) { best = v2; arg = 4 * q + 2; }
+            if (v3 < best) { best = v3; arg = 4 * q + 3; }
+        }
+    }
+    const int nxt = (int)wave_rol1((uint32_t)arg);             // lane l + 1's site (lane 63: lane 0's, not used)
+    const int lo = arg, hi = lane == 63 ? K - 1 : nxt;
+    int trip = hi - lo + 1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) trip = max(trip, __shfl_xor(trip, o));
+    int best[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) best[j] = INT32_MAX;
+    if (K > 0)
+        for (int t = 0; t < trip; ++t) {
+            const uint32_t sv = site(min(lo + t, hi));         // past its own range a lane repeats its last site
+#pragma unroll
+            for (int j = 0; j < 16; ++j) best[j] = min(best[j], cand(sv, 16 * lane + j));
+        }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int x = 16 * lane + j;
+        if (FULL || x < W) out[x] = best[j] >= EDT_F_INF ? INT32_MAX : best[j];
+    }
+    wave_lds_sync();
+    return K;
+}
+
 // ---- edt_band_k16_kernel: rows of 513 .. 1024 pixels (the headline width) -------------------------------------
 // edt_band_g8_kernel<16> with three changes (measured on the wide-row kernel first, whose LDS traffic was its bound):
 //  * the cascade step is add + min3 (two packed instructions per register instead of three, see pk_min3_f16bits);
@@ -1240,9 +1323,9 @@ static int launch_band_wide_t(sc_ctx* ctx, const uint32_t* colbits, int W, int H
 //    that every lane stores ONE dword per two rows instead of two 2-byte pieces each;
 //  * the transposition re-pairs the registers so that a dword holds two ADJACENT pixels: a 16-byte global store is then ONE
 //    8-byte LDS read (half the read traffic of reading packed registers back and keeping one half of every dword).
-template <bool FULL>
+template <bool FULL, bool OPEN>
 __global__ void __launch_bounds__(512, 8)
-edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2) {
+edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, int32_t* __restrict__ d2, const uint32_t* __restrict__ udg) {
     constexpr int WAVES = 8, WP = 1024;
     constexpr uint32_t GC2 = EDT_W_GCAP | (EDT_W_GCAP << 16);
     constexpr uint32_t EDGE = 0x7BFF7BFFu;          // beyond the row ends: above every value, below the f16 NaN patterns
@@ -1359,6 +1442,7 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
     uint32_t* tr = trs + (size_t)wave * 256;
     uint32_t* trb = smem + (size_t)wave * (WP / 4) - 256;      // trb[8 * lane + r] with lane >= 32 lands in row `wave`
     int hint = 4;
+    int open_rows = 0, open_sites = 0;   // OPEN: rows in a row that ended in the site search, and the sites of the last one
     for (int i = wave; i < nrows; i += WAVES) {
         int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
         uint32_t P[8];
@@ -1385,8 +1469,11 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
             for (int j = 0; j < 8; ++j) P[j] = pk_min3_f16bits(P[j], j ? T[j - 1] : L0, j < 7 ? T[j + 1] : RL);
         };
         bool saturated = false;
+        // OPEN: after a row of open space with few sites the wave's next rows go to the site search at once (every eighth
+        // tries the cascade again), as in edt_band_wide_kernel
+        if (OPEN && (open_rows & 7) != 0 && open_sites <= 448) saturated = true;
         int it = 1, next_chk = max(2, hint - 1);
-        for (; it <= EDT_W_ITMAX; ++it) {
+        for (; !saturated && it <= EDT_W_ITMAX; ++it) {
             cascade_step(it);
             const bool last = it == EDT_W_ITMAX;
             if (!last && it < next_chk) continue;
@@ -1409,7 +1496,7 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
             if (__ballot(m > thr) == 0) break;
             if (last) { saturated = true; break; }
         }
-        hint = it;
+        if (!saturated) { hint = it; open_rows = 0; }
         if (!saturated) {
             uint32_t R[8];
 #pragma unroll
@@ -1440,7 +1527,15 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
             }
             wave_lds_sync();
         } else {
-            // ---- 32-bit cascade with exact distances (very sparse rows: some distance beyond 175 columns) ----
+            // ---- the packed cascade cannot settle this row (open space: some distance beyond 175 columns) ----
+            if (OPEN) {
+                // the site search (up / down words from edt_updown_kernel, launched in front of this build) ...
+                ++open_rows;
+                open_sites = edt_k16_site_row<FULL>(cb + (size_t)b * W, udg + ((size_t)g * nb + b) * W, W, i, lane, tr, smem + (size_t)wave * (WP / 4), out);
+                if (lane == 0) g_edt_open[1] = 1;
+                if (open_sites <= 508) continue;
+            } else if (lane == 0) g_edt_open[0] = 1;               // ... which this build leaves to its OPEN twin: tell the host
+            // 32-bit cascade with exact distances (OPEN: rows with more sites than the search's LDS holds)
             uint32_t V[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -1482,11 +1577,43 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
 template <bool FULL>
 static int launch_band_k16(sc_ctx* ctx, const uint32_t* colbits, int W, int H, int nb, int batch, int32_t* d2) {
     const size_t lds = (size_t)32 * 1024 + 8 * 1024;
+    ctx->edt_k16_launched = true;
+    if (ctx->edt_open_mode) {
+        // open space seen on this context (sc_ctx_synchronize): the up / down words first, then the build with the site search
+        int r_ = sc_scratch_reserve(ctx, &ctx->updown, (size_t)batch * nb * W * sizeof(uint32_t));
+        if (r_ != SC_OK) return r_;
+        int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
+        ctx->edt_chain_token = -1;
+        launch_updown(ctx, colbits, W, nb, batch, (uint32_t*)ctx->updown.p);
+        hipLaunchKernelGGL((edt_band_k16_kernel<FULL, true>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream, colbits, W, H, nb, d2,
+                           (const uint32_t*)ctx->updown.p);
+        ctx->edt_open_launched = true;
+        sc_time_end(ctx, tk);
+        SC_HIP(ctx, hipGetLastError());
+        return SC_OK;
+    }
     int tk = ctx->edt_chain_token >= 0 ? sc_time_chain(ctx, ctx->edt_chain_token, SC_K_EDT_BAND) : sc_time_begin(ctx, SC_K_EDT_BAND);
     ctx->edt_chain_token = -1;
-    hipLaunchKernelGGL((edt_band_k16_kernel<FULL>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream, colbits, W, H, nb, d2);
+    hipLaunchKernelGGL((edt_band_k16_kernel<FULL, false>), dim3((unsigned)(nb * batch)), dim3(512), lds, ctx->stream, colbits, W, H, nb, d2,
+                       (const uint32_t*)nullptr);
     sc_time_end(ctx, tk);
     SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+// sc_ctx_synchronize: open space seen / still there?  (Only after a launch of edt_band_k16_kernel on this context.)
+int sc_edt_open_mode_update(sc_ctx* ctx) {
+    if (!ctx->edt_k16_launched) return SC_OK;
+    int32_t h[2] = {0, 0};
+    SC_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_edt_open), sizeof(h)));
+    if (h[0] || h[1]) {
+        const int32_t z[2] = {0, 0};
+        SC_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_edt_open), z, sizeof(z)));
+    }
+    if (h[0]) ctx->edt_open_mode = true;
+    else if (ctx->edt_open_mode && ctx->edt_open_launched && !h[1]) ctx->edt_open_mode = false;
+    ctx->edt_k16_launched = false;
+    ctx->edt_open_launched = false;
     return SC_OK;
 }
 

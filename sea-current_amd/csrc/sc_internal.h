@@ -57,6 +57,8 @@ struct sc_ctx {
     int64_t gather_bytes = 0;       // bytes every rank received in the last gather
     std::set<const void*> big_lds_done;   // kernels whose dynamic-LDS limit this context has raised on its device
     int cu_count = 0;               // compute units of the device (0: not asked yet)
+    bool edt_open_mode = false;     // EDT, rows of 513 .. 1024 pixels: open space seen -> the band kernel's build with the site search
+    bool edt_k16_launched = false, edt_open_launched = false;   // since the last sc_ctx_synchronize
     int astar_waves = 0;            // wavefronts an A* launch keeps resident (0: not yet determined)
     int astar_dual = -1;   // queries the two-wavefront A* kernel keeps resident (-1: not asked yet, 0: off)
     int astar_dual_lat = -1;   // the same for its latency build (larger LDS ring: fewer per CU)
@@ -90,6 +92,7 @@ int sc_allow_big_lds(sc_ctx* ctx, const void* kernel, int bytes);
 
 // wait for everything enqueued on the context's stream without burning a host core
 int sc_stream_wait(sc_ctx* ctx);
+int sc_edt_open_mode_update(sc_ctx* ctx);
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void wave_lds_sync() {

@@ -239,3 +239,26 @@ def test_edt_wide_open_space(ctx, oracle, W):
     tall = (rng.random((1500, W)) < 3e-5).astype(np.uint8)
     tall[0, 0] = 1
     assert np.array_equal(ctx.edt(torch.from_numpy(tall).cuda()).cpu().numpy(), oracle.edt(tall))
+
+
+def test_edt_open_space_mode_up_to_1024_columns(oracle):
+    """Rows of 513 .. 1024 pixels: a context that has met open space (rows the packed cascade cannot settle) runs the band
+    kernel's build with the site search from its next synchronisation on, and goes back once a launch finds none.  Results
+    are the oracle's in every state: first call (32-bit fallback), adapted calls (site search), mixed batches, and back."""
+    import torch
+    import sea_current_amd as sc
+    c = sc.Context(0)
+    rng = np.random.default_rng(77)
+    for W, H in ((1024, 300), (700, 200), (1000, 1100)):
+        sparse = np.stack([(rng.random((H, W)) < p).astype(np.uint8) for p in (2e-5, 1e-4, 4e-4)])
+        sparse[0, H // 2, W // 3] = 1
+        dense = np.stack([(rng.random((H, W)) < 0.2).astype(np.uint8), np.zeros((H, W), np.uint8), sparse[1]])
+        one_col = np.zeros((1, H, W), np.uint8); one_col[0, :, W - 3] = 1
+        refs = {id(a): [oracle.edt(g) for g in a] for a in (sparse, dense, one_col)}
+        for a in (sparse, sparse, sparse, dense, dense, one_col, sparse, dense, dense, dense):
+            got = c.edt(torch.from_numpy(a).cuda())
+            c.synchronize()
+            got = got.cpu().numpy()
+            for k in range(a.shape[0]):
+                assert np.array_equal(got[k], refs[id(a)][k]), (W, H, k)
+    c.close()
