@@ -56,6 +56,8 @@ def make_grid(name, W, H, seed=None):
         return synth.salt_grid(W, H, 0.20, **kw)
     if name == "blocks":
         return synth.block_grid(W, H, 0.20, **kw)
+    if name == "open":     # open space: 2e-5 of the cells occupied, distances of hundreds of cells (EDT legs only)
+        return synth.salt_grid(W, H, 2e-5, **kw)
     raise ValueError(name)
 
 
@@ -353,6 +355,7 @@ def main():
             ctx.set_stream(ts.cuda_stream)
             for _ in range(3):
                 ctx.edt(grids, out=d2b)
+                ctx.synchronize()       # a context adapts to maps of open space when it is synchronised
             ts.synchronize()
             iters = 20
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -415,9 +418,14 @@ def main():
                 pass
         keys = ("achieved", "frac", "ms_per_launch", "ms_colbits_bracketed", "ms_band_bracketed")
         result["roofline_other_maps"] = {k: {kk: v[kk] for kk in keys} for k, v in legs.items() if k != args.map}
+        if not args.only_main_map:
+            open_leg = edt_leg("open", W, H, B)
+            result["roofline_other_maps"]["open"] = {kk: open_leg[kk] for kk in keys}
+            result["roofline_other_maps"]["open"]["note"] = ("2e-5 of the cells occupied: rows the packed cascade cannot settle (distances beyond 175 "
+                                                             "columns) go through the site search; bound by instruction issue, not HBM (DESIGN.md 4.1)")
         if (W, H) == (1024, 1024):   # BASELINE configs[3]'s grid: the same number of cells per launch pair
             result["roofline_4096"] = {fam: {kk: v[kk] for kk in keys + ("workload",)}
-                                       for fam, v in ((f, edt_leg(f, 4096, 4096, max(1, B // 16))) for f in ("salt20", "blocks"))}
+                                       for fam, v in ((f, edt_leg(f, 4096, 4096, max(1, B // 16))) for f in (("salt20", "blocks") if args.only_main_map else ("salt20", "blocks", "open")))}
             # the same kernels on a batch sized for HBM rather than for parity with the 1024^2 leg's byte count: 16 grids = 1.3 GB
             # per launch (a persistent workgroup then runs 16 row groups instead of 4: pipeline fill and launch gaps amortised)
             if B >= 64:
