@@ -85,6 +85,7 @@ def edt_round(ctx, oracle, rng, max_cells=6_000_000):
     if rng.random() < 0.2 and H > 2 and W > 2:
         occ[:] = 0; occ[0, H // 2, W // 2] = 1          # a single obstacle: distances up to the grid diagonal
     d2 = ctx.edt(_t(occ)); torch.cuda.synchronize()
+    ctx.synchronize()          # where a context adapts to maps of open space (and back): every state gets exercised
     got = d2.cpu().numpy()
     for b in range(B):
         ref = oracle.edt(occ[b])
