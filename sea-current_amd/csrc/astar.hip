@@ -303,7 +303,7 @@ __device__ __forceinline__ uint32_t bcast_group8(uint32_t v) {
 //     handed-over nodes at a time, whenever there are any.
 // They meet only when a level is exhausted: wavefront 0 waits until wavefront 1 has nothing left (everything for the
 // later levels is then in their rings) before it picks the next level.  No barrier per step -- the two earlier
-// multi-wavefront forms (tools/microbench/astar_*_experiment.hip.txt) lost exactly there.
+// multi-wavefront forms (four wavefronts per query, a master with workers; round 2, in the history) lost exactly there.
 #ifndef HQ
 #define HQ 256   // records of the hand-over ring
 #endif
