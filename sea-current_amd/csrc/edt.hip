@@ -1307,9 +1307,34 @@ __device__ __forceinline__ int edt_k16_site_row(const uint32_t* __restrict__ cbr
             for (int j = 0; j < 16; ++j) best[j] = min(best[j], cand(sv, 16 * lane + j));
         }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int x = 16 * lane + j;
-        if (FULL || x < W) out[x] = best[j] >= EDT_F_INF ? INT32_MAX : best[j];
+    for (int j = 0; j < 16; ++j) best[j] = best[j] >= EDT_F_INF ? INT32_MAX : best[j];
+    // out through LDS (the sites are no longer needed), half the row at a time: a lane's 16 values are 64 bytes, the row's
+    // lines want 16 bytes per lane from consecutive lanes -- 4 full-line stores instead of 16 that touch a dword of 64 lines each
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        wave_lds_sync();
+        if ((lane >> 5) == p) {
+            uint4* d = reinterpret_cast<uint4*>(((lane & 31) < 16 ? SA : SB) + (lane & 15) * 16);
+            d[0] = make_uint4(best[0], best[1], best[2], best[3]);
+            d[1] = make_uint4(best[4], best[5], best[6], best[7]);
+            d[2] = make_uint4(best[8], best[9], best[10], best[11]);
+            d[3] = make_uint4(best[12], best[13], best[14], best[15]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = 4 * lane + 256 * k;                       // word of this half row
+            const uint4 v = *reinterpret_cast<const uint4*>((k == 0 ? SA : SB) + 4 * lane);
+            const int x = 512 * p + idx;
+            if (FULL || x + 3 < W) {
+                if (FULL || (((uintptr_t)(out + x)) & 15) == 0) EDT_STORE4(out + x, make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w));
+                else { out[x] = (int)v.x; out[x + 1] = (int)v.y; out[x + 2] = (int)v.z; out[x + 3] = (int)v.w; }
+            } else {
+                if (x < W) out[x] = (int)v.x;
+                if (x + 1 < W) out[x + 1] = (int)v.y;
+                if (x + 2 < W) out[x + 2] = (int)v.z;
+            }
+        }
     }
     wave_lds_sync();
     return K;
@@ -1443,6 +1468,22 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
     uint32_t* trb = smem + (size_t)wave * (WP / 4) - 256;      // trb[8 * lane + r] with lane >= 32 lands in row `wave`
     int hint = 4;
     int open_rows = 0, open_sites = 0;   // OPEN: rows in a row that ended in the site search, and the sites of the last one
+    if (OPEN) {
+        // the band's obstacle columns (an obstacle anywhere in the column: the same for all its rows), counted once: what
+        // the site search would cost decides how many steps the cascade gets first (48 + 3 K / 4: from timings of maps of
+        // 2e-5 .. 1e-3 obstacle density -- fewer steps help the sparsest and cost the ones in between)
+        const uint32_t* ubb = udg + ((size_t)g * nb + b) * W + 16 * lane;
+        const uint32_t* cbb = cb + (size_t)b * W + 16 * lane;
+        int cnt = 0;
+        for (int j = 0; j < 16; ++j)
+            if (FULL || 16 * lane + j < W) {
+                const uint32_t ud = ubb[j];
+                cnt += cbb[j] != 0u || (ud & 0xFFFFu) != (uint32_t)EDT_G_INF || (ud >> 16) != (uint32_t)EDT_G_INF;
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+        open_sites = cnt;
+    }
     for (int i = wave; i < nrows; i += WAVES) {
         int32_t* out = d2 + ((size_t)g * H + y0 + i) * W;
         uint32_t P[8];
@@ -1470,12 +1511,17 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
         };
         bool saturated = false;
         // OPEN: after a row of open space with few sites the wave's next rows go to the site search at once (every eighth
-        // tries the cascade again), as in edt_band_wide_kernel
-        if (OPEN && (open_rows & 7) != 0 && open_sites <= 448) saturated = true;
+        // tries the cascade again), as in edt_band_wide_kernel; and the cascade's first try is as long as the search would
+        // cost -- a row with more sites than the search holds comes back and runs the remaining steps
+        bool direct = OPEN && (open_rows & 7) != 0 && open_sites <= 128;
+        if (direct) saturated = true;
         int it = 1, next_chk = max(2, hint - 1);
-        for (; !saturated && it <= EDT_W_ITMAX; ++it) {
+        int it_lim = OPEN ? min(EDT_W_ITMAX, 48 + ((3 * open_sites) >> 2)) : EDT_W_ITMAX;
+        bool row_done = false;
+        for (int attempt = 0;; ++attempt) {
+        for (; !saturated && it <= it_lim; ++it) {
             cascade_step(it);
-            const bool last = it == EDT_W_ITMAX;
+            const bool last = it == it_lim;
             if (!last && it < next_chk) continue;
             next_chk = it + 1 + (it >= 12 ? (it >> 3) : 0);
             uint32_t m;
@@ -1496,6 +1542,20 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
             if (__ballot(m > thr) == 0) break;
             if (last) { saturated = true; break; }
         }
+        if (!OPEN || !saturated || attempt == 1) break;
+        // OPEN, not settled (or not tried): the site search
+        ++open_rows;
+        open_sites = edt_k16_site_row<FULL>(cb + (size_t)b * W, udg + ((size_t)g * nb + b) * W, W, i, lane, tr, smem + (size_t)wave * (WP / 4), out);
+        if (lane == 0) g_edt_open[1] = 1;
+        if (open_sites <= 508) { row_done = true; break; }
+        // more sites than the search's LDS holds: the rest of the 175 steps after all
+        it = direct ? 1 : it + 1;
+        next_chk = it;
+        it_lim = EDT_W_ITMAX;
+        saturated = false;
+        direct = false;
+        }
+        if (OPEN && row_done) continue;
         if (!saturated) { hint = it; open_rows = 0; }
         if (!saturated) {
             uint32_t R[8];
@@ -1528,13 +1588,7 @@ edt_band_k16_kernel(const uint32_t* __restrict__ colbits, int W, int H, int nb, 
             wave_lds_sync();
         } else {
             // ---- the packed cascade cannot settle this row (open space: some distance beyond 175 columns) ----
-            if (OPEN) {
-                // the site search (up / down words from edt_updown_kernel, launched in front of this build) ...
-                ++open_rows;
-                open_sites = edt_k16_site_row<FULL>(cb + (size_t)b * W, udg + ((size_t)g * nb + b) * W, W, i, lane, tr, smem + (size_t)wave * (WP / 4), out);
-                if (lane == 0) g_edt_open[1] = 1;
-                if (open_sites <= 508) continue;
-            } else if (lane == 0) g_edt_open[0] = 1;               // ... which this build leaves to its OPEN twin: tell the host
+            if (!OPEN && lane == 0) g_edt_open[0] = 1;             // the site search is in this kernel's OPEN twin: tell the host
             // 32-bit cascade with exact distances (OPEN: rows with more sites than the search's LDS holds)
             uint32_t V[16];
 #pragma unroll
