@@ -86,6 +86,10 @@ int sc_ctx_destroy(sc_ctx* ctx);
 int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream (the default after create). */
 int sc_ctx_use_own_stream(sc_ctx* ctx);
+/* Wait for everything enqueued on the context's stream.  Also where a context adapts to what its launches met: A* rings
+ * that overflowed (later calls start with larger ones), maps of open space at widths of 513 .. 1024 (later EDTs run the
+ * band kernel's build with the site search, until a launch meets none), and where a wide-row EDT whose bounded waits ran
+ * out is reported (SC_ERR_HIP).  Results never depend on the adapted state. */
 int sc_ctx_synchronize(sc_ctx* ctx);
 /* Kernel timing: when enabled every kernel launch is bracketed by HIP events on
  * the context's stream; sc_ctx_get_timing synchronises and returns the summed
