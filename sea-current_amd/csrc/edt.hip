@@ -973,6 +973,7 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
         // Open space shows before the first step: 23 adjacent lanes of one stretch whose 16 pixels all carry the clamped
         // distance (368 columns without an obstacle within 176 rows) hold a pixel that no 175 steps can settle -- straight
         // to the site search below instead of 175 steps first.  (Sufficient, not necessary: other rows find out at the end.)
+        int nopen = 0;                              // lanes (of 64 TILES) whose 16 pixels all carry the clamped distance
         {
             constexpr uint32_t OPEN2 = (EDT_W_GCAP * EDT_W_GCAP) * 0x00010001u;
 #pragma unroll
@@ -981,18 +982,21 @@ edt_band_wide_kernel(const uint32_t* __restrict__ colbits, const uint32_t* __res
 #pragma unroll
                 for (int j = 0; j < 8; ++j) open16 = open16 && P[t][j] == OPEN2;
                 unsigned long long r = __ballot(open16);
+                nopen += __popcll(r);
                 r &= r >> 1; r &= r >> 2; r &= r >> 4; r &= r >> 8; r &= r >> 7;      // runs of 2, 4, 8, 16, 23 lanes
                 if (r) saturated = true;
             }
         }
+        // ... and a row three quarters of which has no obstacle within 176 rows gets 48 steps, not 175, before it changes over
+        const int it_cap = 4 * nopen >= 3 * 64 * TILES ? 48 : EDT_W_ITMAX;
         // After a row of open space with few sites (the search then costs less than the 175 steps that settled nothing) the
         // wave's next rows go to the site search at once, except every eighth, which tries the cascade again.  (A row that
         // would have settled costs at most about twice as much that way; maps without open space never get here.)
         if ((open_rows & 7) != 0 && open_sites <= 512) saturated = true;
         int it = 1, next_chk = max(2, min(hint - 1, 8));
-        for (; !saturated && it <= EDT_W_ITMAX; ++it) {
+        for (; !saturated && it <= it_cap; ++it) {
             cascade_step(it);
-            const bool last = it == EDT_W_ITMAX;
+            const bool last = it == it_cap;
             if (!last && it < next_chk) continue;
             next_chk = it + 1 + (it >= 12 ? (it >> 3) : 0);
             uint32_t m = 0;
